@@ -1,0 +1,87 @@
+"""Generate golden vectors by IMPORTING the reference's own python modules.
+
+Run in the authoring container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes small .npz fixtures next to this file; they travel to the GPU box, the
+reference does not.  Reference modules used (the only ones importable without
+jax/flax/absl/svox):
+  octree/nerf/model_utils.py  (MLP, posenc)
+  octree/nerf/models.py       (NerfModel.eval_points_raw)
+  nerf_sh/nerf/sh.py          (eval_sh)
+"""
+import os
+import sys
+import importlib.util
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    sys.path.insert(0, REF)
+    from octree.nerf import model_utils as ref_mu          # noqa: E402
+    from octree.nerf import models as ref_models           # noqa: E402
+    ref_sh = _load("ref_sh", os.path.join(REF, "nerf_sh/nerf/sh.py"))
+
+    torch.manual_seed(20200823)
+    rng = np.random.default_rng(7)
+
+    # ---- posenc -----------------------------------------------------------
+    x = torch.tensor(rng.uniform(-4.0, 4.0, size=(37, 3)), dtype=torch.float32)
+    x[0] = 0.0
+    enc = ref_mu.posenc(x, 0, 10)
+    np.savez(os.path.join(HERE, "posenc.npz"), x=x.numpy(), enc=enc.numpy())
+
+    # ---- eval_points_raw for SH16 and SH25 --------------------------------
+    for deg in (3, 4):
+        K = (deg + 1) ** 2
+        model = ref_models.NerfModel(
+            num_coarse_samples=64, num_fine_samples=128, use_viewdirs=False, sh_deg=deg,
+            sg_dim=-1, num_rgb_channels=3 * K, num_sigma_channels=1)
+        # non-zero biases so that the bias path is exercised
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.1, 0.1)
+        pts = torch.tensor(rng.uniform(-1.5, 1.5, size=(96, 3)), dtype=torch.float32)
+        with torch.no_grad():
+            rgb_f, sig_f = model.eval_points_raw(pts)
+            rgb_c, sig_c = model.eval_points_raw(pts, coarse=True)
+        out = dict(points=pts.numpy(), raw_rgb_fine=rgb_f.numpy(), raw_sigma_fine=sig_f.numpy(),
+                   raw_rgb_coarse=rgb_c.numpy(), raw_sigma_coarse=sig_c.numpy())
+        # parameters in flax key order / kernel [in,out] (octree/nerf/models.py:75-102)
+        for mi, mlp in enumerate((model.MLP_0, model.MLP_1)):
+            layers = list(mlp.input_layers) + [mlp.sigma_layer, mlp.rgb_layer]
+            for li, layer in enumerate(layers):
+                out[f"MLP_{mi}.Dense_{li}.kernel"] = layer.weight.detach().numpy().T.copy()
+                out[f"MLP_{mi}.Dense_{li}.bias"] = layer.bias.detach().numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f"eval_points_sh{K}.npz"), **out)
+
+    # ---- eval_sh deg 0..4 -------------------------------------------------
+    out = {}
+    d = rng.normal(size=(29, 3))
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    out["dirs"] = d.astype(np.float32)
+    for deg in range(5):
+        K = (deg + 1) ** 2
+        sh = rng.normal(size=(29, 5, 3, K)).astype(np.float32)
+        res = ref_sh.eval_sh(deg, torch.tensor(sh), torch.tensor(out["dirs"])[:, None])
+        out[f"sh_{deg}"] = sh
+        out[f"res_{deg}"] = res.numpy()
+    np.savez(os.path.join(HERE, "eval_sh.npz"), **out)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

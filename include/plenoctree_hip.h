@@ -1,0 +1,200 @@
+/*
+ * plenoctree_hip.h -- C ABI of the MI355X (gfx950) NeRF-SH hot path.
+ *
+ * The reference (sxyu/plenoctree) has no FFI of its own: its hot path is a Python call
+ * surface (JAX/Flax, and a torch twin for extraction).  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree).  Everything
+ * is extern "C", plain pointers and sizes; device pointers are caller-owned (e.g. torch
+ * ROCm storage), no hidden allocation (workspace sizes are queried, then passed in), every
+ * call is asynchronous on the hipStream_t given as `void* stream`.
+ *
+ * Return value: 0 = ok, negative = error (message via pxo_last_error()).
+ *
+ * Layouts (all float32, row-major):
+ *   rays      origins/directions/viewdirs [B,3]         (nerf_sh/nerf/utils.py:53 Rays)
+ *   params    flat arena per model: MLP_0{Dense_0..9 kernel[in,out],bias[out]}, MLP_1{...}
+ *             Dense_0..7 trunk, Dense_8 sigma head, Dense_9 rgb head
+ *             (key order of octree/nerf/models.py:91-102); see pxo_param_layout().
+ *   raw_rgb   [M,3K] channel-major then SH coefficient (nerf_sh/nerf/models.py:269-272)
+ *   raw_sigma [M]
+ */
+#ifndef PLENOCTREE_HIP_H_
+#define PLENOCTREE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXO_OK 0
+#define PXO_ERR_ARG (-1)
+#define PXO_ERR_HIP (-2)
+#define PXO_ERR_WORKSPACE (-3)
+#define PXO_ERR_UNSUPPORTED (-4)
+
+#define PXO_NET_DEPTH 8
+#define PXO_NET_WIDTH 256
+#define PXO_SKIP_LAYER 4
+#define PXO_ENC_DIM 63      /* 3*(1+2*10), nerf_sh/nerf/model_utils.py:145-173 */
+#define PXO_ENC_PAD 64
+#define PXO_TILE_ROWS 128   /* rows (samples) per workgroup in the fused MLP kernels */
+#define PXO_NUM_LEAVES 20   /* per MLP: 10 x (kernel, bias) */
+
+/* Hyper-parameters of the path: the flags of nerf_sh/nerf/utils.py:61-230 that reach the
+ * model (NerfModel fields, nerf_sh/nerf/models.py:55-78) and the loss (train.py:77-85). */
+typedef struct PxoCfg {
+  int32_t num_coarse_samples;  /* 64  */
+  int32_t num_fine_samples;    /* 128 (0 = coarse only) */
+  int32_t sh_deg;              /* 0..4; K=(deg+1)^2 */
+  int32_t min_deg_point;       /* must be 0  */
+  int32_t max_deg_point;       /* must be 10 */
+  int32_t white_bkgd;
+  int32_t lindisp;
+  int32_t sparsity_npoints;    /* 10000 */
+  float near_;
+  float far_;
+  float sparsity_weight;       /* 1e-3; 0 disables the branch (train.py:77) */
+  float sparsity_length;       /* 0.05 */
+  float sparsity_radius;       /* 1.5 */
+  float weight_decay_mult;     /* 0 */
+} PxoCfg;
+
+/* One leaf of the parameter arena (offsets in floats, relative to ONE MLP's sub-arena). */
+typedef struct PxoLeaf {
+  int32_t layer;      /* Dense_<layer> */
+  int32_t is_bias;
+  int64_t offset;
+  int32_t rows;       /* kernel: in ; bias: out */
+  int32_t cols;       /* kernel: out; bias: 1   */
+} PxoLeaf;
+
+const char* pxo_last_error(void);
+int pxo_version(void);
+
+/* Parameter arena description (flax pytree flattened; replaces the pytree walk of
+ * octree/nerf/models.py:75-102).  leaves must hold PXO_NUM_LEAVES entries. */
+int pxo_param_layout(const PxoCfg* cfg, PxoLeaf* leaves, int64_t* floats_per_mlp);
+
+/* Sizes (in floats) of the MFMA-fragment-ordered weight images of ONE MLP. */
+int pxo_packed_sizes(const PxoCfg* cfg, int64_t* fwd_floats, int64_t* bwd_floats);
+/* Re-order one MLP's parameters into the fragment order the fused kernels stream.
+ * Must be re-run after every parameter update.  bwd image may be NULL (inference). */
+int pxo_pack_weights(const PxoCfg* cfg, const float* mlp_params, float* packed_fwd,
+                     float* packed_bwd, void* stream);
+
+/* ---- stage-level entry points (unit-parity hooks against the oracle) -------------- */
+
+/* sample_along_rays + cast_rays, nerf_sh/nerf/model_utils.py:104-142,:97-101.
+ * t_rand [B,S] in [0,1) or NULL (randomized=False). z_vals [B,S], pts [B*S,3]. */
+int pxo_sample_along_rays(const float* origins, const float* directions, int64_t B, int S,
+                          float near_, float far_, int lindisp, const float* t_rand,
+                          float* z_vals, float* pts, void* stream);
+
+/* posenc(x, 0, 10), nerf_sh/nerf/model_utils.py:145-173. enc [N,63]. */
+int pxo_posenc(const float* x, int64_t N, float* enc, void* stream);
+
+/* Fused posenc + MLP.__call__ (nerf_sh/nerf/model_utils.py:43-94, condition=None;
+ * torch twin octree/nerf/model_utils.py:87-158) over M points.
+ * raw_rgb [M,3K] may be NULL (sigma only).  Training outputs, all set or all NULL:
+ *   acts      8 x [M,256] post-ReLU activations (inputs of the weight-gradient GEMMs)
+ *   enc       [M,64] encoded inputs (63 + one zero column)
+ *   relu_mask opaque 1-bit/activation image in the kernels' fragment order,
+ *             pxo_relu_mask_bytes(M) bytes; consumed by pxo_mlp_bwd_data. */
+size_t pxo_relu_mask_bytes(int64_t M);
+int pxo_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
+                float* raw_rgb, float* raw_sigma, float* acts, float* enc, void* relu_mask,
+                void* stream);
+
+/* Reverse of pxo_mlp_fwd w.r.t. the trunk (jax.value_and_grad, nerf_sh/train.py:116): writes
+ * dz (8 x [M,256], gradient at each layer's pre-activation) and per-tile bias-gradient
+ * partials (pxo_dbias_partial_bytes(M) bytes) for pxo_mlp_bwd_weights. */
+size_t pxo_dbias_partial_bytes(int64_t M);
+int pxo_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
+                     const float* d_raw_sigma, const void* relu_mask, int64_t M, float* dz,
+                     float* dbias_partial, void* stream);
+
+/* Parameter gradients of one MLP from saved activations and dz; grads has the layout of
+ * one MLP's sub-arena and is overwritten.  ws: pxo_wgrad_workspace_bytes(). */
+int pxo_wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M, size_t* bytes);
+int pxo_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
+                        const float* d_raw_rgb, const float* d_raw_sigma,
+                        const float* dbias_partial, int64_t M, float* grads, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* eval_sh + sigmoid + relu + volumetric_rendering (nerf_sh/nerf/sh.py:54-109,
+ * nerf_sh/nerf/models.py:269-284, nerf_sh/nerf/model_utils.py:176-222) for B rays of S
+ * samples.  Outputs comp_rgb [B,3], disp [B], acc [B], weights [B,S]. */
+int pxo_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma,
+                            const float* z_vals, const float* directions, const float* viewdirs,
+                            int64_t B, int S, float* comp_rgb, float* disp, float* acc,
+                            float* weights, void* stream);
+/* Its reverse for a loss that depends on comp_rgb only (nerf_sh/train.py:89-98):
+ * d_comp_rgb [B,3] -> d_raw_rgb [B*S,3K], d_raw_sigma [B*S]. */
+int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma,
+                            const float* z_vals, const float* directions, const float* viewdirs,
+                            const float* d_comp_rgb, int64_t B, int S, float* d_raw_rgb,
+                            float* d_raw_sigma, void* stream);
+
+/* sample_pdf (piecewise_constant_pdf + sort + cast_rays), nerf_sh/nerf/model_utils.py:225-314
+ * with bins/weights derived as in nerf_sh/nerf/models.py:296-301.
+ * z_coarse, w_coarse [B,Nc]; u [B,Nf] in [0,1) or NULL (randomized=False).
+ * z_out [B,Nc+Nf] ascending, pts [B*(Nc+Nf),3]. */
+int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* origins,
+                   const float* directions, int64_t B, int Nc, int Nf, const float* u,
+                   float* z_out, float* pts, void* stream);
+
+/* Counter-based uniform generator (Philox4x32-10) replacing jax.random.uniform call sites
+ * (nerf_sh/nerf/model_utils.py:135,262; nerf_sh/train.py:79).  out[i] in [lo,hi). */
+int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out,
+                void* stream);
+
+/* flax.optim.Adam.apply_gradient (call site nerf_sh/train.py:119; beta1 .9, beta2 .999,
+ * eps 1e-8), with g = grads*grad_scale (grad_scale = 1/world_size after an RCCL sum).
+ * `step` = number of updates already applied. */
+int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t n, float lr,
+                  int64_t step, float grad_scale, void* stream);
+
+/* ---- whole-path entry points ------------------------------------------------------ */
+
+/* NerfModel.__call__ forward only (nerf_sh/nerf/models.py:216-348; called by
+ * get_render_pfn nerf_sh/nerf/utils.py:701-713).  packed_fwd0/1: images of MLP_0/MLP_1.
+ * t_rand/u as above (NULL with randomized!=0 draws them from `seed`).
+ * Outputs [B,3],[B],[B] for coarse and fine (fine ones may be NULL if num_fine_samples==0). */
+int pxo_render_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes);
+int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* packed_fwd1,
+                   const float* origins, const float* directions, const float* viewdirs,
+                   int64_t B, int randomized, const float* t_rand, const float* u, uint64_t seed,
+                   float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f,
+                   float* acc_f, void* ws, size_t ws_bytes, void* stream);
+
+/* loss_fn + value_and_grad of train_step (nerf_sh/train.py:66-116) on this device's shard.
+ * params: the 2-MLP arena; packed_*: its images (pxo_pack_weights).  grads: 2-MLP arena,
+ * overwritten with d(total loss)/d(params).  stats[6] (device) = loss, psnr, loss_c,
+ * loss_sp, psnr_c, weight_l2 (Stats, nerf_sh/nerf/utils.py:43-50).
+ * sp_points [npoints,3] or NULL (drawn from seed).  The cross-device mean (pmean,
+ * train.py:117-118) and Adam are the caller's next two steps. */
+int pxo_train_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes);
+int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packed_fwd0,
+                      const float* packed_bwd0, const float* packed_fwd1,
+                      const float* packed_bwd1, const float* origins, const float* directions,
+                      const float* viewdirs, const float* pixels, int64_t B, int randomized,
+                      const float* t_rand, const float* u, const float* sp_points, uint64_t seed,
+                      float* grads, float* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* NerfModel.eval_points_raw (octree/nerf/models.py:211-252; call sites
+ * octree/extraction.py:271,316,373).  raw_rgb may be NULL (step1 keeps sigma only). */
+int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* points, int64_t N,
+                    float* raw_rgb, float* raw_sigma, void* stream);
+
+/* Dense-grid driver of octree/extraction.py:290-320 (step1) / :250-274 (auto_scale):
+ * evaluates sigma at grid point ((i+.5)/reso - offset[a]) / scale[a] for x in [x0,x1),
+ * all y,z (ij meshgrid order, x slowest).  sigma_out [(x1-x0)*reso*reso]. */
+int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
+                   const float offset[3], const float scale[3], float* sigma_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLENOCTREE_HIP_H_ */

@@ -1,0 +1,129 @@
+"""ctypes binding of libplenoctree_hip.so (include/plenoctree_hip.h).
+
+The library is the product path: there is no CPU fallback.  Loading fails loudly if the
+shared object is missing, and every call raises PxoError on a non-zero status.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_uint64, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplenoctree_hip.so")
+
+NET_DEPTH = 8
+NET_WIDTH = 256
+ENC_DIM = 63
+ENC_PAD = 64
+TILE_ROWS = 128
+NUM_LEAVES = 20
+
+
+class PxoError(RuntimeError):
+    pass
+
+
+class PxoCfg(Structure):
+    _fields_ = [
+        ("num_coarse_samples", c_int32),
+        ("num_fine_samples", c_int32),
+        ("sh_deg", c_int32),
+        ("min_deg_point", c_int32),
+        ("max_deg_point", c_int32),
+        ("white_bkgd", c_int32),
+        ("lindisp", c_int32),
+        ("sparsity_npoints", c_int32),
+        ("near_", c_float),
+        ("far_", c_float),
+        ("sparsity_weight", c_float),
+        ("sparsity_length", c_float),
+        ("sparsity_radius", c_float),
+        ("weight_decay_mult", c_float),
+    ]
+
+
+class PxoLeaf(Structure):
+    _fields_ = [
+        ("layer", c_int32),
+        ("is_bias", c_int32),
+        ("offset", c_int64),
+        ("rows", c_int32),
+        ("cols", c_int32),
+    ]
+
+
+P = c_void_p
+CFG = POINTER(PxoCfg)
+
+# name -> (restype, argtypes); must list every symbol include/plenoctree_hip.h declares
+SIGNATURES = {
+    "pxo_last_error": (c_char_p, []),
+    "pxo_version": (c_int, []),
+    "pxo_param_layout": (c_int, [CFG, POINTER(PxoLeaf), POINTER(c_int64)]),
+    "pxo_packed_sizes": (c_int, [CFG, POINTER(c_int64), POINTER(c_int64)]),
+    "pxo_pack_weights": (c_int, [CFG, P, P, P, P]),
+    "pxo_sample_along_rays": (c_int, [P, P, c_int64, c_int, c_float, c_float, c_int, P, P, P, P]),
+    "pxo_posenc": (c_int, [P, c_int64, P, P]),
+    "pxo_relu_mask_bytes": (c_size_t, [c_int64]),
+    "pxo_mlp_fwd": (c_int, [CFG, P, P, c_int64, P, P, P, P, P, P]),
+    "pxo_dbias_partial_bytes": (c_size_t, [c_int64]),
+    "pxo_mlp_bwd_data": (c_int, [CFG, P, P, P, P, c_int64, P, P, P]),
+    "pxo_wgrad_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
+    "pxo_mlp_bwd_weights": (c_int, [CFG, P, P, P, P, P, P, c_int64, P, P, c_size_t, P]),
+    "pxo_shade_composite_fwd": (c_int, [CFG, P, P, P, P, P, c_int64, c_int, P, P, P, P, P]),
+    "pxo_shade_composite_bwd": (c_int, [CFG, P, P, P, P, P, P, c_int64, c_int, P, P, P]),
+    "pxo_sample_pdf": (c_int, [P, P, P, P, c_int64, c_int, c_int, P, P, P, P]),
+    "pxo_uniform": (c_int, [c_uint64, c_uint64, c_int64, c_float, c_float, P, P]),
+    "pxo_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_int64, c_float, P]),
+    "pxo_render_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
+    "pxo_render_fwd": (c_int, [CFG, P, P, P, P, P, c_int64, c_int, P, P, c_uint64, P, P, P, P, P, P, P,
+                               c_size_t, P]),
+    "pxo_train_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
+    "pxo_train_fwd_bwd": (c_int, [CFG, P, P, P, P, P, P, P, P, P, c_int64, c_int, P, P, P, c_uint64, P, P,
+                                  P, c_size_t, P]),
+    "pxo_eval_points": (c_int, [CFG, P, P, c_int64, P, P, P]),
+    "pxo_grid_sigma": (c_int, [CFG, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise PxoError(
+            f"{path} not found: build it with `python -m plenoctree_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pxo_last_error()
+        raise PxoError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def make_cfg(**kw):
+    """PxoCfg with the defaults of nerf_sh/config/blender.yaml over nerf_sh/nerf/utils.py:61-230."""
+    vals = dict(num_coarse_samples=64, num_fine_samples=128, sh_deg=3, min_deg_point=0, max_deg_point=10,
+                white_bkgd=1, lindisp=0, sparsity_npoints=10000, near_=2.0, far_=6.0,
+                sparsity_weight=1e-3, sparsity_length=0.05, sparsity_radius=1.5, weight_decay_mult=0.0)
+    for k, v in kw.items():
+        if k not in vals:
+            raise ValueError(f"unknown PxoCfg field {k}")
+        vals[k] = v
+    cfg = PxoCfg()
+    for k, v in vals.items():
+        setattr(cfg, k, int(v) if k not in ("near_", "far_", "sparsity_weight", "sparsity_length",
+                                            "sparsity_radius", "weight_decay_mult") else float(v))
+    return cfg

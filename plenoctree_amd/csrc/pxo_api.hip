@@ -1,0 +1,418 @@
+// C ABI of the gfx950 NeRF-SH hot path (see include/plenoctree_hip.h).  Host-side glue only:
+// argument checks, workspace carving and the kernel sequences of NerfModel.__call__
+// (nerf_sh/nerf/models.py:216-348) and loss_fn/value_and_grad (nerf_sh/train.py:66-116).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "pxo_common.h"
+
+namespace pxo {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PXO_ERR_HIP;
+  }
+  return PXO_OK;
+}
+
+int validate_cfg(const PxoCfg* cfg) {
+  PXO_REQUIRE(cfg != nullptr, "cfg is NULL");
+  PXO_REQUIRE(cfg->sh_deg >= 0 && cfg->sh_deg <= 4, "sh_deg %d not in [0,4] (nerf_sh/nerf/sh.py:69)", cfg->sh_deg);
+  PXO_REQUIRE(cfg->min_deg_point == 0 && cfg->max_deg_point == 10,
+              "only min_deg_point=0,max_deg_point=10 is built (got %d,%d)", cfg->min_deg_point, cfg->max_deg_point);
+  PXO_REQUIRE(cfg->num_coarse_samples >= 3 && cfg->num_coarse_samples <= 128, "num_coarse_samples %d not in [3,128]",
+              cfg->num_coarse_samples);
+  PXO_REQUIRE(cfg->num_fine_samples >= 0 && cfg->num_coarse_samples + cfg->num_fine_samples <= 256,
+              "num_coarse_samples+num_fine_samples must be <= 256");
+  return PXO_OK;
+}
+
+int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1, const float* off,
+                        const float* scale, float* sigma_out, hipStream_t s);
+
+// bump allocator over the caller's workspace; with base == nullptr it only measures
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <typename T>
+  T* take(int64_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (size_t)count * sizeof(T);
+    return p;
+  }
+};
+
+struct PassBuffers {      // one MLP pass (coarse or fine)
+  int64_t M = 0;          // rows through the MLP (ray samples + appended sparsity points)
+  int S = 0;              // samples per ray
+  float *z, *pts, *raw_rgb, *raw_sigma, *acts, *enc, *comp_rgb, *disp, *acc, *weights;
+  uint32_t* mask;
+  float *d_comp, *d_raw_rgb, *d_raw_sigma, *dz, *dbias;
+};
+
+static void carve_pass(Carver& c, PassBuffers& p, int64_t B, int S, int64_t extra_rows, int C, bool train,
+                       bool own_outputs) {
+  p.S = S;
+  p.M = B * S + extra_rows;
+  p.z = c.take<float>(B * S);
+  p.pts = c.take<float>(p.M * 3);
+  p.raw_rgb = c.take<float>(p.M * C);
+  p.raw_sigma = c.take<float>(p.M);
+  p.weights = c.take<float>(B * S);
+  if (own_outputs) {
+    p.comp_rgb = c.take<float>(B * 3);
+    p.disp = c.take<float>(B);
+    p.acc = c.take<float>(B);
+  }
+  if (train) {
+    p.acts = c.take<float>(p.M * kW * kDepth);
+    p.enc = c.take<float>(p.M * kEncPad);
+    p.mask = c.take<uint32_t>(mask_words(p.M));
+    p.d_comp = c.take<float>(B * 3);
+    p.d_raw_rgb = c.take<float>(p.M * C);
+    p.d_raw_sigma = c.take<float>(p.M);
+    p.dz = c.take<float>(p.M * kW * kDepth);
+    p.dbias = c.take<float>(dbias_floats(p.M));
+  } else {
+    p.acts = p.enc = p.d_comp = p.d_raw_rgb = p.d_raw_sigma = p.dz = p.dbias = nullptr;
+    p.mask = nullptr;
+  }
+}
+
+struct TrainWs {
+  PassBuffers c, f;
+  float *t_rand, *u, *sp, *scalars;
+  void* wgrad_ws;
+  size_t wgrad_bytes;
+  int64_t n_sp;
+  size_t total;
+};
+
+static void carve_train(const PxoCfg* cfg, int64_t B, void* ws, bool train, TrainWs& t) {
+  Carver c(ws);
+  const int C = rgb_channels(cfg->sh_deg);
+  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  const bool sp = train && cfg->sparsity_weight > 0.f && cfg->sparsity_npoints > 0;
+  t.n_sp = sp ? cfg->sparsity_npoints : 0;
+  // eval_points_raw uses MLP_1 when there is a fine pass (nerf_sh/nerf/models.py:165-168), so the
+  // sparsity points ride along as extra rows of the last pass.
+  carve_pass(c, t.c, B, Nc, Nf > 0 ? 0 : t.n_sp, C, train, train);
+  if (Nf > 0) carve_pass(c, t.f, B, Nc + Nf, t.n_sp, C, train, train);
+  t.t_rand = c.take<float>(B * Nc);
+  t.u = c.take<float>(B * (Nf > 0 ? Nf : 1));
+  t.sp = c.take<float>(t.n_sp * 3 + 4);
+  t.scalars = c.take<float>(128);
+  if (train) {
+    const int64_t Mmax = Nf > 0 ? t.f.M : t.c.M;
+    t.wgrad_bytes = wgrad_workspace_bytes(cfg, Mmax);
+    t.wgrad_ws = c.take<char>((int64_t)t.wgrad_bytes);
+  } else {
+    t.wgrad_bytes = 0;
+    t.wgrad_ws = nullptr;
+  }
+  t.total = (c.off + 255) & ~(size_t)255;
+}
+
+#define PXO_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != PXO_OK) return _rc; \
+  } while (0)
+
+// forward of NerfModel.__call__ into the pass buffers; returns via p the intermediate tensors
+static int run_forward(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* pk1, const float* o,
+                       const float* d, const float* v, int64_t B, int randomized, const float* t_rand,
+                       const float* u, const float* sp_points, uint64_t seed, bool train, float* rgb_c,
+                       float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f, hipStream_t s) {
+  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  if (randomized && !t_rand) {
+    PXO_TRY(launch_uniform(seed, 0, B * Nc, 0.f, 1.f, t.t_rand, s));
+    t_rand = t.t_rand;
+  }
+  if (!randomized) t_rand = nullptr;
+  if (randomized && Nf > 0 && !u) {
+    PXO_TRY(launch_uniform(seed, 1, B * Nf, 0.f, 1.f, t.u, s));
+    u = t.u;
+  }
+  if (!randomized) u = nullptr;
+  PassBuffers& last = Nf > 0 ? t.f : t.c;
+  if (t.n_sp > 0) {
+    float* dst = last.pts + B * last.S * 3;
+    if (sp_points) {
+      if (hipMemcpyAsync(dst, sp_points, (size_t)t.n_sp * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        set_error("hipMemcpyAsync(sp_points) failed");
+        return PXO_ERR_HIP;
+      }
+    } else {
+      PXO_TRY(launch_uniform(seed, 2, t.n_sp * 3, -cfg->sparsity_radius, cfg->sparsity_radius, dst, s));
+    }
+  }
+  // coarse pass
+  PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, t_rand, t.c.z, t.c.pts, s));
+  PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s));
+  PXO_TRY(launch_shade_composite_fwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, B, Nc, rgb_c, disp_c, acc_c,
+                                     t.c.weights, s));
+  if (Nf > 0) {
+    PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, u, t.f.z, t.f.pts, s));
+    PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
+    PXO_TRY(launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f,
+                                       acc_f, t.f.weights, s));
+  }
+  (void)train;
+  return PXO_OK;
+}
+
+}  // namespace pxo
+
+using namespace pxo;
+
+extern "C" {
+
+const char* pxo_last_error(void) { return g_last_error.c_str(); }
+int pxo_version(void) { return 1; }
+
+int pxo_param_layout(const PxoCfg* cfg, PxoLeaf* leaves, int64_t* floats_per_mlp) {
+  PXO_TRY(validate_cfg(cfg));
+  const int deg = cfg->sh_deg;
+  if (leaves) {
+    for (int l = 0; l < 10; ++l) {
+      leaves[2 * l] = PxoLeaf{l, 0, leaf_kernel_off(l, deg), layer_in(l), layer_out(l, deg)};
+      leaves[2 * l + 1] = PxoLeaf{l, 1, leaf_bias_off(l, deg), layer_out(l, deg), 1};
+    }
+  }
+  if (floats_per_mlp) *floats_per_mlp = mlp_param_count(deg);
+  return PXO_OK;
+}
+
+int pxo_packed_sizes(const PxoCfg* cfg, int64_t* fwd_floats, int64_t* bwd_floats) {
+  PXO_TRY(validate_cfg(cfg));
+  if (fwd_floats) *fwd_floats = fwd_image_floats(cfg->sh_deg);
+  if (bwd_floats) *bwd_floats = bwd_image_floats(cfg->sh_deg);
+  return PXO_OK;
+}
+
+int pxo_pack_weights(const PxoCfg* cfg, const float* mlp_params, float* packed_fwd, float* packed_bwd, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(mlp_params && packed_fwd, "pxo_pack_weights: NULL pointer");
+  return launch_pack(cfg, mlp_params, packed_fwd, packed_bwd, (hipStream_t)stream);
+}
+
+int pxo_sample_along_rays(const float* origins, const float* directions, int64_t B, int S, float near_, float far_,
+                          int lindisp, const float* t_rand, float* z_vals, float* pts, void* stream) {
+  PXO_REQUIRE(B >= 0 && S >= 1, "pxo_sample_along_rays: bad sizes B=%lld S=%d", (long long)B, S);
+  PXO_REQUIRE(origins && directions && z_vals && pts, "pxo_sample_along_rays: NULL pointer");
+  return launch_sample_along_rays(origins, directions, B, S, near_, far_, lindisp, t_rand, z_vals, pts,
+                                  (hipStream_t)stream);
+}
+
+int pxo_posenc(const float* x, int64_t N, float* enc, void* stream) {
+  PXO_REQUIRE(N >= 0 && x && enc, "pxo_posenc: bad arguments");
+  return launch_posenc(x, N, enc, (hipStream_t)stream);
+}
+
+size_t pxo_relu_mask_bytes(int64_t M) { return (size_t)mask_words(M) * sizeof(uint32_t); }
+size_t pxo_dbias_partial_bytes(int64_t M) { return (size_t)dbias_floats(M) * sizeof(float); }
+
+int pxo_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M, float* raw_rgb,
+                float* raw_sigma, float* acts, float* enc, void* relu_mask, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(M >= 0 && packed_fwd && pts && raw_sigma, "pxo_mlp_fwd: bad arguments");
+  PXO_REQUIRE((acts != nullptr) == (enc != nullptr) && (acts != nullptr) == (relu_mask != nullptr),
+              "pxo_mlp_fwd: acts, enc and relu_mask must be all set or all NULL");
+  return launch_mlp_fwd(cfg, packed_fwd, pts, M, raw_rgb, raw_sigma, acts, enc, (uint32_t*)relu_mask,
+                        (hipStream_t)stream);
+}
+
+int pxo_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
+                     const void* relu_mask, int64_t M, float* dz, float* dbias_partial, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(M >= 0 && packed_bwd && d_raw_rgb && d_raw_sigma && relu_mask && dz && dbias_partial,
+              "pxo_mlp_bwd_data: bad arguments");
+  return launch_mlp_bwd_data(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, (const uint32_t*)relu_mask, M, dz,
+                             dbias_partial, (hipStream_t)stream);
+}
+
+int pxo_wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M, size_t* bytes) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(bytes && M >= 0, "pxo_wgrad_workspace_bytes: bad arguments");
+  *bytes = wgrad_workspace_bytes(cfg, M > 0 ? M : 1);
+  return PXO_OK;
+}
+
+int pxo_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
+                        const float* d_raw_rgb, const float* d_raw_sigma, const float* dbias_partial, int64_t M,
+                        float* grads, void* ws, size_t ws_bytes, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(M >= 0 && acts && enc && dz && d_raw_rgb && d_raw_sigma && dbias_partial && grads && ws,
+              "pxo_mlp_bwd_weights: bad arguments");
+  return launch_mlp_bwd_weights(cfg, acts, enc, dz, d_raw_rgb, d_raw_sigma, dbias_partial, M, grads, ws, ws_bytes,
+                                (hipStream_t)stream);
+}
+
+int pxo_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z_vals,
+                            const float* directions, const float* viewdirs, int64_t B, int S, float* comp_rgb,
+                            float* disp, float* acc, float* weights, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(B >= 0 && raw_rgb && raw_sigma && z_vals && directions && viewdirs && comp_rgb && disp && acc && weights,
+              "pxo_shade_composite_fwd: bad arguments");
+  return launch_shade_composite_fwd(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, B, S, comp_rgb, disp, acc,
+                                    weights, (hipStream_t)stream);
+}
+
+int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z_vals,
+                            const float* directions, const float* viewdirs, const float* d_comp_rgb, int64_t B, int S,
+                            float* d_raw_rgb, float* d_raw_sigma, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(B >= 0 && raw_rgb && raw_sigma && z_vals && directions && viewdirs && d_comp_rgb && d_raw_rgb &&
+                  d_raw_sigma,
+              "pxo_shade_composite_bwd: bad arguments");
+  return launch_shade_composite_bwd(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, d_comp_rgb, B, S,
+                                    d_raw_rgb, d_raw_sigma, (hipStream_t)stream);
+}
+
+int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* origins, const float* directions,
+                   int64_t B, int Nc, int Nf, const float* u, float* z_out, float* pts, void* stream) {
+  PXO_REQUIRE(B >= 0 && z_coarse && w_coarse && origins && directions && z_out && pts, "pxo_sample_pdf: bad arguments");
+  return launch_sample_pdf(z_coarse, w_coarse, origins, directions, B, Nc, Nf, u, z_out, pts, (hipStream_t)stream);
+}
+
+int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, void* stream) {
+  PXO_REQUIRE(n >= 0 && out, "pxo_uniform: bad arguments");
+  return launch_uniform(seed, stream_id, n, lo, hi, out, (hipStream_t)stream);
+}
+
+int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t n, float lr, int64_t step,
+                  float grad_scale, void* stream) {
+  PXO_REQUIRE(n >= 0 && params && m && v && grads && step >= 0, "pxo_adam_step: bad arguments");
+  return launch_adam(params, m, v, grads, n, lr, step, grad_scale, (hipStream_t)stream);
+}
+
+int pxo_render_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(bytes && B >= 0, "pxo_render_workspace_bytes: bad arguments");
+  TrainWs t;
+  carve_train(cfg, B, nullptr, false, t);
+  *bytes = t.total;
+  return PXO_OK;
+}
+
+int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* packed_fwd1, const float* origins,
+                   const float* directions, const float* viewdirs, int64_t B, int randomized, const float* t_rand,
+                   const float* u, uint64_t seed, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f,
+                   float* disp_f, float* acc_f, void* ws, size_t ws_bytes, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(B >= 0 && packed_fwd0 && origins && directions && viewdirs && rgb_c && disp_c && acc_c && ws,
+              "pxo_render_fwd: bad arguments");
+  if (cfg->num_fine_samples > 0)
+    PXO_REQUIRE(packed_fwd1 && rgb_f && disp_f && acc_f, "pxo_render_fwd: fine outputs/weights missing");
+  TrainWs t;
+  carve_train(cfg, B, ws, false, t);
+  if (ws_bytes < t.total) {
+    set_error("pxo_render_fwd: workspace %zu < %zu", ws_bytes, t.total);
+    return PXO_ERR_WORKSPACE;
+  }
+  if (B == 0) return PXO_OK;
+  return run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
+                     nullptr, seed, false, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, (hipStream_t)stream);
+}
+
+int pxo_train_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(bytes && B >= 1, "pxo_train_workspace_bytes: bad arguments");
+  TrainWs t;
+  carve_train(cfg, B, nullptr, true, t);
+  *bytes = t.total;
+  return PXO_OK;
+}
+
+int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packed_fwd0, const float* packed_bwd0,
+                      const float* packed_fwd1, const float* packed_bwd1, const float* origins,
+                      const float* directions, const float* viewdirs, const float* pixels, int64_t B, int randomized,
+                      const float* t_rand, const float* u, const float* sp_points, uint64_t seed, float* grads,
+                      float* stats, void* ws, size_t ws_bytes, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(B >= 1 && params && packed_fwd0 && packed_bwd0 && origins && directions && viewdirs && pixels && grads &&
+                  stats && ws,
+              "pxo_train_fwd_bwd: bad arguments");
+  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  if (Nf > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
+  hipStream_t s = (hipStream_t)stream;
+  TrainWs t;
+  carve_train(cfg, B, ws, true, t);
+  if (ws_bytes < t.total) {
+    set_error("pxo_train_fwd_bwd: workspace %zu < %zu", ws_bytes, t.total);
+    return PXO_ERR_WORKSPACE;
+  }
+  const int deg = cfg->sh_deg, C = rgb_channels(deg);
+  const int64_t n_mlp = mlp_param_count(deg);
+  PXO_TRY(run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
+                      sp_points, seed, true, t.c.comp_rgb, t.c.disp, t.c.acc, Nf > 0 ? t.f.comp_rgb : nullptr,
+                      Nf > 0 ? t.f.disp : nullptr, Nf > 0 ? t.f.acc : nullptr, s));
+  // scalars: [0] sse_f, [1] sse_c, [2] sum_exp, [3..] sumsq (+scratch)
+  float* sc = t.scalars;
+  PassBuffers& last = Nf > 0 ? t.f : t.c;
+  // losses (train.py:89-98): fine + coarse MSE
+  PXO_TRY(launch_mse_grad(t.c.comp_rgb, pixels, B, t.c.d_comp, sc + 1, s));
+  if (Nf > 0) PXO_TRY(launch_mse_grad(t.f.comp_rgb, pixels, B, t.f.d_comp, sc + 0, s));
+  PXO_TRY(launch_shade_composite_bwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, directions, viewdirs, t.c.d_comp, B, Nc,
+                                     t.c.d_raw_rgb, t.c.d_raw_sigma, s));
+  if (Nf > 0)
+    PXO_TRY(launch_shade_composite_bwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, directions, viewdirs, t.f.d_comp, B,
+                                       Nc + Nf, t.f.d_raw_rgb, t.f.d_raw_sigma, s));
+  if (t.n_sp > 0) {  // sparsity rows (train.py:77-85): gradient on sigma only
+    const int64_t r0 = B * last.S;
+    PXO_TRY(launch_sparsity_grad(last.raw_sigma + r0, t.n_sp, cfg->sparsity_weight, cfg->sparsity_length,
+                                 last.d_raw_sigma + r0, sc + 2, s));
+    PXO_TRY(launch_fill(last.d_raw_rgb + r0 * C, t.n_sp * C, 0.f, s));
+  }
+  // reverse through the MLPs
+  PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, s));
+  PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
+                                 grads, t.wgrad_ws, t.wgrad_bytes, s));
+  if (Nf > 0) {
+    PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, s));
+    PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
+                                   grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, s));
+  } else {
+    PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
+  }
+  PXO_TRY(launch_sumsq(params, 2 * n_mlp, sc + 3, s));
+  PXO_TRY(launch_finalize_stats(sc + 0, sc + 1, sc + 2, sc + 3, B, Nf > 0, t.n_sp, cfg->sparsity_weight, 2 * n_mlp,
+                                stats, s));
+  return PXO_OK;
+}
+
+int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* points, int64_t N, float* raw_rgb,
+                    float* raw_sigma, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(N >= 0 && packed_fwd && points && raw_sigma, "pxo_eval_points: bad arguments");
+  return launch_mlp_fwd(cfg, packed_fwd, points, N, raw_rgb, raw_sigma, nullptr, nullptr, nullptr,
+                        (hipStream_t)stream);
+}
+
+int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1, const float offset[3],
+                   const float scale[3], float* sigma_out, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(packed_fwd && offset && scale && sigma_out, "pxo_grid_sigma: NULL pointer");
+  PXO_REQUIRE(reso >= 1 && x0 >= 0 && x1 >= x0 && x1 <= reso, "pxo_grid_sigma: bad slab [%d,%d) of %d", x0, x1, reso);
+  return launch_mlp_fwd_grid(cfg, packed_fwd, reso, x0, x1, offset, scale, sigma_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

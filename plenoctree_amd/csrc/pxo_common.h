@@ -1,0 +1,147 @@
+// Shared host/device definitions for the gfx950 NeRF-SH kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/plenoctree_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace pxo {
+
+constexpr int kW = PXO_NET_WIDTH;        // 256
+constexpr int kDepth = PXO_NET_DEPTH;    // 8
+constexpr int kEnc = PXO_ENC_DIM;        // 63
+constexpr int kEncPad = PXO_ENC_PAD;     // 64
+constexpr int kTM = PXO_TILE_ROWS;       // 128 rows per workgroup
+constexpr int kLDA = 260;                // LDS row stride (floats): 256 + one b128 access of pad
+constexpr int kFwdThreads = 256;         // 4 waves, each 128 rows x 64 cols
+constexpr int kFwdWaves = kFwdThreads / 64;
+constexpr int kCPW = 8 / kFwdWaves;      // 32-col blocks per wave in a 256-wide layer
+constexpr int kMaskWords = 4 * kCPW * 16 / 32;  // relu-mask words per thread per layer
+
+// ---- derived sizes -----------------------------------------------------------------
+__host__ __device__ inline int sh_dim(int deg) { return (deg + 1) * (deg + 1); }
+__host__ __device__ inline int rgb_channels(int deg) { return 3 * sh_dim(deg); }
+// head width padded to 32-col MFMA blocks: cols [0,3K) = Dense_9 (rgb), col 3K = Dense_8 (sigma)
+__host__ __device__ inline int head_blocks(int deg) { return (rgb_channels(deg) + 1 + 31) / 32; }
+
+// input rows of Dense_l (l = 0..9) in the reference layout
+__host__ __device__ inline int layer_in(int l) {
+  return l == 0 ? kEnc : (l == 5 ? kW + kEnc : kW);
+}
+__host__ __device__ inline int layer_out(int l, int deg) {
+  return l < 8 ? kW : (l == 8 ? 1 : rgb_channels(deg));
+}
+// offset (floats) of Dense_l kernel inside ONE MLP's sub-arena; bias follows its kernel
+__host__ __device__ inline int64_t leaf_kernel_off(int l, int deg) {
+  int64_t off = 0;
+  for (int i = 0; i < l; ++i) off += (int64_t)layer_in(i) * layer_out(i, deg) + layer_out(i, deg);
+  return off;
+}
+__host__ __device__ inline int64_t leaf_bias_off(int l, int deg) {
+  return leaf_kernel_off(l, deg) + (int64_t)layer_in(l) * layer_out(l, deg);
+}
+__host__ __device__ inline int64_t mlp_param_count(int deg) { return leaf_kernel_off(10, deg); }
+
+// ---- packed (MFMA fragment order) weight images --------------------------------------
+// A packed matrix B[K][N] (K = 8*KG, N = 32*NCB) stores element (k,n) at
+//   ((g*NCB + c)*64 + lane)*4 + j,  g=k/8, lane=((k%8)/4)*32 + n%32, j=k%4, c=n/32
+// so that one wave reads a (k-group, col-block) fragment as 64 lanes x 16 B contiguous and
+// lane l feeds mfma_f32_32x32x2f32 number j with B[k=8g+4*(l>>5)+j][n=32c+(l&31)].
+__host__ __device__ inline int64_t packed_index(int k, int n, int ncb) {
+  int g = k >> 3, kk = k & 7;
+  int lane = ((kk >> 2) << 5) | (n & 31);
+  return (((int64_t)g * ncb + (n >> 5)) * 64 + lane) * 4 + (kk & 3);
+}
+
+// forward image: trunk layer l (0..7) then heads then biases
+__host__ __device__ inline int fwd_kgroups(int l) { return l == 0 ? 8 : (l == 5 ? 40 : 32); }
+__host__ __device__ inline int64_t fwd_layer_off(int l) {  // l in 0..8 (8 = heads)
+  int64_t off = 0;
+  for (int i = 0; i < l; ++i) off += (int64_t)fwd_kgroups(i) * 8 * 256;
+  return off;
+}
+__host__ __device__ inline int64_t fwd_bias_off(int deg) {
+  return fwd_layer_off(8) + (int64_t)32 * head_blocks(deg) * 256;
+}
+__host__ __device__ inline int64_t fwd_image_floats(int deg) {
+  return fwd_bias_off(deg) + 8 * kW + 32 * head_blocks(deg);
+}
+// backward(data) image: head^T (K = 32*NHB, N = 256), then W_l^T for l = 7..1 (K = 256 outputs,
+// N = first 256 inputs)
+__host__ __device__ inline int64_t bwd_layer_off(int l, int deg) {  // l in 1..7
+  return (int64_t)head_blocks(deg) * 32 * 256 + (int64_t)(7 - l) * 256 * 256;
+}
+__host__ __device__ inline int64_t bwd_image_floats(int deg) { return bwd_layer_off(0, deg); }
+
+// relu-mask image written by the forward kernel: per (tile, layer, thread) kMaskWords words
+__host__ __device__ inline int64_t num_tiles(int64_t M) { return (M + kTM - 1) / kTM; }
+__host__ __device__ inline int64_t mask_words(int64_t M) {
+  return num_tiles(M) * kDepth * kFwdThreads * kMaskWords;
+}
+// per-tile bias-gradient partials written by the backward-data kernel: [tile][9][256]
+__host__ __device__ inline int64_t dbias_floats(int64_t M) { return num_tiles(M) * 9 * kW; }
+
+// ---- error plumbing ------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PXO_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      pxo::set_error(__VA_ARGS__);        \
+      return PXO_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+
+int validate_cfg(const PxoCfg* cfg);
+
+// ---- launchers implemented in the kernel translation units -----------------------------
+int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s);
+int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
+                   float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
+                   hipStream_t s);
+int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
+                        const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
+                        float* dbias_partial, hipStream_t s);
+size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
+int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
+                           const float* d_raw_rgb, const float* d_raw_sigma,
+                           const float* dbias_partial, int64_t M, float* grads, void* ws,
+                           size_t ws_bytes, hipStream_t s);
+int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
+int launch_grid_points(int reso, int x0, int x1, const float* off_scale /*6 floats, device*/,
+                       float* pts, hipStream_t s);
+
+int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_,
+                             float far_, int lindisp, const float* t_rand, float* z, float* pts,
+                             hipStream_t s);
+int launch_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma,
+                               const float* z, const float* dirs, const float* viewdirs, int64_t B,
+                               int S, float* comp_rgb, float* disp, float* acc, float* weights,
+                               hipStream_t s);
+int launch_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma,
+                               const float* z, const float* dirs, const float* viewdirs,
+                               const float* d_comp_rgb, int64_t B, int S, float* d_raw_rgb,
+                               float* d_raw_sigma, hipStream_t s);
+int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const float* d, int64_t B,
+                      int Nc, int Nf, const float* u, float* z_out, float* pts, hipStream_t s);
+int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out,
+                   hipStream_t s);
+int launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, int64_t step,
+                float grad_scale, hipStream_t s);
+// d_rgb = 2*(rgb-px)/(3B); partial[0] = sum((rgb-px)^2) (deterministic single-block reduce)
+int launch_mse_grad(const float* rgb, const float* pixels, int64_t B, float* d_rgb, float* sse_out,
+                    hipStream_t s);
+// sparsity branch (train.py:77-85): d_raw_sigma for the appended rows + sum(exp(-len*relu(s)))
+int launch_sparsity_grad(const float* raw_sigma, int64_t n, float weight, float length,
+                         float* d_raw_sigma, float* sum_exp_out, hipStream_t s);
+int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);
+int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* sum_exp,
+                          const float* sumsq, int64_t B, int has_fine, int64_t n_sp, float sp_weight,
+                          int64_t n_params, float* stats, hipStream_t s);
+int launch_fill(float* p, int64_t n, float v, hipStream_t s);
+
+}  // namespace pxo

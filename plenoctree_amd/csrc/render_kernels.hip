@@ -1,0 +1,456 @@
+// Wavefront-parallel ray kernels for gfx950: stratified sampling, SH shading + alpha compositing
+// (forward and reverse), hierarchical PDF resampling + sort, and the counter-based uniform
+// generator.  One 64-lane wave per ray; compositing uses a wave product-scan (DPP shuffles).
+//
+// Reference semantics: nerf_sh/nerf/model_utils.py:97-314, nerf_sh/nerf/sh.py:54-109,
+// nerf_sh/nerf/models.py:269-307.
+#include "pxo_common.h"
+
+namespace pxo {
+
+constexpr int kRayThreads = 256;             // 4 rays per workgroup
+constexpr int kRaysPerBlock = kRayThreads / 64;
+
+// torch/jnp.linspace(start, end, n)[i] in float32 (symmetric evaluation like ATen's kernel)
+__device__ __forceinline__ float linspace_at(float start, float end, int n, int i) {
+  if (n <= 1) return start;
+  const float step = (end - start) / (float)(n - 1);
+  return i < n / 2 ? start + step * (float)i : end - step * (float)(n - 1 - i);
+}
+
+// ------------------------------------------------------------------------------------------
+// sample_along_rays + cast_rays (model_utils.py:104-142, :97-101)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coarse_z(int s, int S, float near_, float far_, int lindisp) {
+  const float t = linspace_at(0.f, 1.f, S, s);
+  if (lindisp) return 1.f / (1.f / near_ * (1.f - t) + 1.f / far_ * t);
+  return near_ * (1.f - t) + far_ * t;
+}
+
+__global__ void sample_along_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                         int64_t B, int S, float near_, float far_, int lindisp,
+                                         const float* __restrict__ t_rand, float* __restrict__ z_out,
+                                         float* __restrict__ pts) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= B * S) return;
+  const int64_t b = idx / S;
+  const int s = (int)(idx - b * S);
+  float z = coarse_z(s, S, near_, far_, lindisp);
+  if (t_rand) {
+    const float lower = s == 0 ? z : 0.5f * (z + coarse_z(s - 1, S, near_, far_, lindisp));
+    const float upper = s == S - 1 ? z : 0.5f * (coarse_z(s + 1, S, near_, far_, lindisp) + z);
+    z = lower + (upper - lower) * t_rand[idx];
+  }
+  z_out[idx] = z;
+  pts[idx * 3 + 0] = o[b * 3 + 0] + z * d[b * 3 + 0];
+  pts[idx * 3 + 1] = o[b * 3 + 1] + z * d[b * 3 + 1];
+  pts[idx * 3 + 2] = o[b * 3 + 2] + z * d[b * 3 + 2];
+}
+
+int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_, float far_,
+                             int lindisp, const float* t_rand, float* z, float* pts, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  const int64_t n = B * S;
+  hipLaunchKernelGGL(sample_along_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, d, B, S,
+                     near_, far_, lindisp, t_rand, z, pts);
+  return check_launch("sample_along_rays");
+}
+
+// ------------------------------------------------------------------------------------------
+// SH basis (nerf_sh/nerf/sh.py:24-52, :72-108): multipliers of sh[..., k]
+// ------------------------------------------------------------------------------------------
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[(DEG + 1) * (DEG + 1)]) {
+  Y[0] = 0.28209479177387814f;
+  if constexpr (DEG > 0) {
+    Y[1] = -0.4886025119029199f * y;
+    Y[2] = 0.4886025119029199f * z;
+    Y[3] = -0.4886025119029199f * x;
+  }
+  if constexpr (DEG > 1) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Y[4] = 1.0925484305920792f * xy;
+    Y[5] = -1.0925484305920792f * yz;
+    Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    Y[7] = -1.0925484305920792f * xz;
+    Y[8] = 0.5462742152960396f * (xx - yy);
+    if constexpr (DEG > 2) {
+      Y[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+      Y[10] = 2.890611442640554f * xy * z;
+      Y[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+      Y[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+      Y[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+      Y[14] = 1.445305721320277f * z * (xx - yy);
+      Y[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+    }
+    if constexpr (DEG > 3) {
+      Y[16] = 2.5033429417967046f * xy * (xx - yy);
+      Y[17] = -1.7701307697799304f * yz * (3.f * xx - yy);
+      Y[18] = 0.9461746957575601f * xy * (7.f * zz - 1.f);
+      Y[19] = -0.6690465435572892f * yz * (7.f * zz - 3.f);
+      Y[20] = 0.10578554691520431f * (zz * (35.f * zz - 30.f) + 3.f);
+      Y[21] = -0.6690465435572892f * xz * (7.f * zz - 3.f);
+      Y[22] = 0.47308734787878004f * (xx - yy) * (7.f * zz - 1.f);
+      Y[23] = -1.7701307697799304f * xz * (xx - 3.f * yy);
+      Y[24] = 0.6258357354491761f * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+// inclusive product scan across the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off);
+    if (lane >= off) v *= t;
+  }
+  return v;
+}
+// inclusive sum scan towards lane 0 (suffix sums)
+__device__ __forceinline__ float wave_rscan_add(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_down(v, off);
+    if (lane + off < 64) v += t;
+  }
+  return v;
+}
+
+constexpr int kMaxChunks = 4;  // up to 256 samples per ray
+
+// per-lane state of one 64-sample chunk of a ray
+struct SampleState {
+  float rgb[3];
+  float e;      // exp(-sigma*dist)
+  float T;      // transmittance before this sample
+  float z;
+  float dist;
+  float raw_sigma;
+};
+
+// loads the chunk's raw SH coefficients through LDS (coalesced), evaluates sigmoid(eval_sh),
+// relu(sigma), alpha and the transmittance scan; `carry` is the product over previous chunks.
+template <int DEG>
+__device__ __forceinline__ void shade_chunk(const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma,
+                                            const float* __restrict__ z_vals, float* __restrict__ wl,
+                                            const float (&Y)[(DEG + 1) * (DEG + 1)], int64_t ray, int S,
+                                            int ch, int lane, float norm_d, float& carry, SampleState& st) {
+  constexpr int K = (DEG + 1) * (DEG + 1), C = 3 * K, CS = C | 1;
+  const int s0 = ch * 64;
+  const int nvalid = S - s0 < 64 ? S - s0 : 64;
+  const int64_t base = ray * S + s0;
+  __syncthreads();
+  for (int idx = lane; idx < nvalid * C; idx += 64) {
+    const int s = idx / C, j = idx - s * C;
+    wl[s * CS + j] = raw_rgb[base * C + idx];
+  }
+  __syncthreads();
+  const bool valid = lane < nvalid;
+  float f = 1.f;
+  st.e = 1.f; st.z = 0.f; st.dist = 0.f; st.raw_sigma = 0.f;
+  st.rgb[0] = st.rgb[1] = st.rgb[2] = 0.f;
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float pre = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) pre += Y[k] * wl[lane * CS + c * K + k];
+      st.rgb[c] = 1.f / (1.f + expf(-pre));        // sigmoid, models.py:280
+    }
+    st.raw_sigma = raw_sigma[base + lane];
+    const float sigma = fmaxf(st.raw_sigma, 0.f);  // relu, models.py:281
+    st.z = z_vals[base + lane];
+    const bool last = (s0 + lane == S - 1);
+    st.dist = (last ? 1e10f : z_vals[base + lane + 1] - st.z) * norm_d;
+    st.e = expf(-sigma * st.dist);
+    f = (1.f - (1.f - st.e)) + 1e-10f;             // 1 - alpha + eps, model_utils.py:202
+  }
+  const float incl = wave_scan_mul(f, lane);
+  float excl = __shfl_up(incl, 1);
+  if (lane == 0) excl = 1.f;
+  st.T = carry * excl;
+  carry = carry * __shfl(incl, 63);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kRayThreads) void shade_composite_fwd_kernel(
+    const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma, const float* __restrict__ z_vals,
+    const float* __restrict__ dirs, const float* __restrict__ viewdirs, int64_t B, int S, int white,
+    float* __restrict__ comp_rgb, float* __restrict__ disp, float* __restrict__ acc_out,
+    float* __restrict__ weights) {
+  constexpr int K = (DEG + 1) * (DEG + 1), C = 3 * K, CS = C | 1;
+  __shared__ float lds[kRaysPerBlock][64 * CS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t ray = blockIdx.x * (int64_t)kRaysPerBlock + wave;
+  const bool ray_ok = ray < B;
+  if (!ray_ok) ray = B - 1;
+  float Y[K];
+  sh_basis<DEG>(viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], Y);
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float norm_d = sqrtf(dx * dx + dy * dy + dz * dz);
+  float carry = 1.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;
+  const int nch = (S + 63) / 64;
+  for (int ch = 0; ch < nch; ++ch) {
+    SampleState st;
+    shade_chunk<DEG>(raw_rgb, raw_sigma, z_vals, lds[wave], Y, ray, S, ch, lane, norm_d, carry, st);
+    const float w = (1.f - st.e) * st.T;
+    s_r += w * st.rgb[0]; s_g += w * st.rgb[1]; s_b += w * st.rgb[2];
+    s_depth += w * st.z; s_acc += w;
+    if (ray_ok && ch * 64 + lane < S) weights[ray * S + ch * 64 + lane] = w;
+  }
+  s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b);
+  s_depth = wave_sum(s_depth); s_acc = wave_sum(s_acc);
+  if (ray_ok && lane == 0) {
+    const float inv_eps = 1e10f;
+    float dsp = s_acc / s_depth;
+    dsp = (dsp > 0.f && dsp < inv_eps && s_acc > 1e-10f) ? dsp : inv_eps;  // model_utils.py:217-219
+    const float bg = white ? 1.f - s_acc : 0.f;
+    comp_rgb[ray * 3 + 0] = s_r + bg;
+    comp_rgb[ray * 3 + 1] = s_g + bg;
+    comp_rgb[ray * 3 + 2] = s_b + bg;
+    disp[ray] = dsp;
+    acc_out[ray] = s_acc;
+  }
+}
+
+// reverse of the above for a loss on comp_rgb only; no gradient flows to z (stop_gradient,
+// model_utils.py:286, and the stratified z are parameter-free).
+template <int DEG>
+__global__ __launch_bounds__(kRayThreads) void shade_composite_bwd_kernel(
+    const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma, const float* __restrict__ z_vals,
+    const float* __restrict__ dirs, const float* __restrict__ viewdirs, const float* __restrict__ d_comp,
+    int64_t B, int S, int white, float* __restrict__ d_raw_rgb, float* __restrict__ d_raw_sigma) {
+  constexpr int K = (DEG + 1) * (DEG + 1), C = 3 * K, CS = C | 1;
+  __shared__ float lds[kRaysPerBlock][64 * CS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t ray = blockIdx.x * (int64_t)kRaysPerBlock + wave;
+  const bool ray_ok = ray < B;
+  if (!ray_ok) ray = B - 1;
+  float Y[K];
+  sh_basis<DEG>(viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], Y);
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float norm_d = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float g0 = d_comp[ray * 3], g1 = d_comp[ray * 3 + 1], g2 = d_comp[ray * 3 + 2];
+  const float bgc = white ? 1.f : 0.f;
+  const int nch = (S + 63) / 64;
+  SampleState st[kMaxChunks];
+  float carry = 1.f;
+#pragma unroll
+  for (int ch = 0; ch < kMaxChunks; ++ch)
+    if (ch < nch) shade_chunk<DEG>(raw_rgb, raw_sigma, z_vals, lds[wave], Y, ray, S, ch, lane, norm_d, carry, st[ch]);
+  float suffix = 0.f;  // sum over later samples of dL/dw_j * w_j
+#pragma unroll
+  for (int ch = kMaxChunks - 1; ch >= 0; --ch) {
+    if (ch >= nch) continue;
+    const SampleState& q = st[ch];
+    const bool valid = ch * 64 + lane < S;
+    const float alpha = 1.f - q.e;
+    const float w = alpha * q.T;
+    // comp = sum_s w_s c_s + bg*(1 - sum_s w_s)
+    const float dw = g0 * (q.rgb[0] - bgc) + g1 * (q.rgb[1] - bgc) + g2 * (q.rgb[2] - bgc);
+    const float G = valid ? dw * w : 0.f;
+    const float incl = wave_rscan_add(G, lane);
+    float excl = __shfl_down(incl, 1);
+    if (lane == 63) excl = 0.f;
+    const float R = suffix + excl;
+    suffix += __shfl(incl, 0);
+    const float fct = (1.f - alpha) + 1e-10f;
+    const float dalpha = dw * q.T - R / fct;
+    const float dsigma = dalpha * q.dist * q.e;     // d(1-exp(-s*dist))/ds
+    const int64_t base = ray * S + ch * 64;
+    if (ray_ok && valid) d_raw_sigma[base + lane] = q.raw_sigma > 0.f ? dsigma : 0.f;
+    __syncthreads();
+    if (valid) {
+      const float dp[3] = {g0 * w * q.rgb[0] * (1.f - q.rgb[0]), g1 * w * q.rgb[1] * (1.f - q.rgb[1]),
+                           g2 * w * q.rgb[2] * (1.f - q.rgb[2])};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave][lane * CS + c * K + k] = dp[c] * Y[k];
+    }
+    __syncthreads();
+    const int nvalid = S - ch * 64 < 64 ? S - ch * 64 : 64;
+    if (ray_ok)
+      for (int idx = lane; idx < nvalid * C; idx += 64) {
+        const int s = idx / C, j = idx - s * C;
+        d_raw_rgb[base * C + idx] = lds[wave][s * CS + j];
+      }
+  }
+}
+
+#define PXO_DEG_SWITCH(deg, CALL) \
+  switch (deg) {                  \
+    case 0: CALL(0); break;       \
+    case 1: CALL(1); break;       \
+    case 2: CALL(2); break;       \
+    case 3: CALL(3); break;       \
+    default: CALL(4); break;      \
+  }
+
+int launch_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z,
+                               const float* dirs, const float* viewdirs, int64_t B, int S, float* comp_rgb,
+                               float* disp, float* acc, float* weights, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  if (S > 64 * kMaxChunks || S < 1) { set_error("samples per ray %d not in [1,%d]", S, 64 * kMaxChunks); return PXO_ERR_ARG; }
+  dim3 grid((unsigned)((B + kRaysPerBlock - 1) / kRaysPerBlock)), block(kRayThreads);
+#define CALL(D) hipLaunchKernelGGL((shade_composite_fwd_kernel<D>), grid, block, 0, s, raw_rgb, raw_sigma, z, dirs, \
+                                   viewdirs, B, S, cfg->white_bkgd, comp_rgb, disp, acc, weights)
+  PXO_DEG_SWITCH(cfg->sh_deg, CALL)
+#undef CALL
+  return check_launch("shade_composite_fwd");
+}
+
+int launch_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z,
+                               const float* dirs, const float* viewdirs, const float* d_comp_rgb, int64_t B, int S,
+                               float* d_raw_rgb, float* d_raw_sigma, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  if (S > 64 * kMaxChunks || S < 1) { set_error("samples per ray %d not in [1,%d]", S, 64 * kMaxChunks); return PXO_ERR_ARG; }
+  dim3 grid((unsigned)((B + kRaysPerBlock - 1) / kRaysPerBlock)), block(kRayThreads);
+#define CALL(D) hipLaunchKernelGGL((shade_composite_bwd_kernel<D>), grid, block, 0, s, raw_rgb, raw_sigma, z, dirs, \
+                                   viewdirs, d_comp_rgb, B, S, cfg->white_bkgd, d_raw_rgb, d_raw_sigma)
+  PXO_DEG_SWITCH(cfg->sh_deg, CALL)
+#undef CALL
+  return check_launch("shade_composite_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// sample_pdf: piecewise_constant_pdf + sort + cast_rays (model_utils.py:225-314), with
+// bins = mid-points of z_coarse and weights = w_coarse[1:-1] (models.py:296-301)
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxCoarse = 128, kMaxFine = 256;
+
+__global__ __launch_bounds__(kRayThreads) void sample_pdf_kernel(
+    const float* __restrict__ z_c, const float* __restrict__ w_c, const float* __restrict__ o,
+    const float* __restrict__ d, int64_t B, int Nc, int Nf, const float* __restrict__ u_in,
+    float* __restrict__ z_out, float* __restrict__ pts) {
+  __shared__ float s_cdf[kRaysPerBlock][kMaxCoarse];
+  __shared__ float s_bins[kRaysPerBlock][kMaxCoarse];
+  __shared__ float s_pdf[kRaysPerBlock][kMaxCoarse];
+  __shared__ float s_z[kRaysPerBlock][kMaxCoarse + kMaxFine];
+  __shared__ float s_sorted[kRaysPerBlock][kMaxCoarse + kMaxFine];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t ray = blockIdx.x * (int64_t)kRaysPerBlock + wave;
+  const bool ray_ok = ray < B;
+  if (!ray_ok) ray = B - 1;
+  const int nb = Nc - 1;   // knots
+  const int nw = Nc - 2;   // weights / bins between knots
+  float* cdf = s_cdf[wave]; float* bins = s_bins[wave]; float* pdf = s_pdf[wave];
+  float* zall = s_z[wave]; float* sorted = s_sorted[wave];
+
+  float wsum = 0.f;
+  for (int i = lane; i < Nc; i += 64) {
+    const float zi = z_c[ray * Nc + i];
+    zall[i] = zi;
+    if (i + 1 < Nc) bins[i] = 0.5f * (z_c[ray * Nc + i + 1] + zi);   // models.py:296
+    if (i >= 1 && i <= nw) { const float wi = w_c[ray * Nc + i]; pdf[i - 1] = wi; wsum += wi; }
+  }
+  wsum = wave_sum(wsum);
+  // model_utils.py:240-244: pad so that the sum is at least eps
+  const float padding = fmaxf(0.f, 1e-5f - wsum);
+  const float wtot = wsum + padding;
+  __syncthreads();
+  for (int i = lane; i < nw; i += 64) pdf[i] = (pdf[i] + padding / (float)nw) / wtot;
+  __syncthreads();
+  if (lane == 0) {  // sequential cumsum keeps the cdf monotone (model_utils.py:248-257)
+    float run = 0.f;
+    cdf[0] = 0.f;
+    for (int i = 0; i + 1 < nw; ++i) { run += pdf[i]; cdf[i + 1] = fminf(1.f, run); }
+    cdf[nw] = 1.f;
+  }
+  __syncthreads();
+  const float u_hi = 1.f - 1.1920928955078125e-07f;   // 1 - finfo(float32).eps, model_utils.py:265
+  for (int f = lane; f < Nf; f += 64) {
+    const float u = u_in ? u_in[ray * Nf + f] : linspace_at(0.f, u_hi, Nf, f);
+    int cnt = 0;
+    for (int k = 0; k < nb; ++k) cnt += (u >= cdf[k]) ? 1 : 0;      // mask = u >= cdf (:270)
+    int k0 = cnt - 1; if (k0 < 0) k0 = 0;
+    int k1 = cnt < nb ? cnt : nb - 1;
+    const float c0 = cdf[k0], c1 = cdf[k1], b0 = bins[k0], b1 = bins[k1];
+    float t = (u - c0) / (c1 - c0);
+    if (t != t) t = 0.f;                                            // nan_to_num (:282)
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    zall[Nc + f] = b0 + t * (b1 - b0);
+  }
+  __syncthreads();
+  const int n = Nc + Nf;
+  for (int e = lane; e < n; e += 64) {   // rank sort: a sort is a permutation, values stay exact
+    const float x = zall[e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float y = zall[j];
+      rank += (y < x || (y == x && j < e)) ? 1 : 0;
+    }
+    sorted[rank] = x;
+  }
+  __syncthreads();
+  if (ray_ok) {
+    const float ox = o[ray * 3], oy = o[ray * 3 + 1], oz = o[ray * 3 + 2];
+    const float dx = d[ray * 3], dy = d[ray * 3 + 1], dz = d[ray * 3 + 2];
+    for (int e = lane; e < n; e += 64) {
+      const float z = sorted[e];
+      const int64_t idx = ray * n + e;
+      z_out[idx] = z;
+      pts[idx * 3 + 0] = ox + z * dx;
+      pts[idx * 3 + 1] = oy + z * dy;
+      pts[idx * 3 + 2] = oz + z * dz;
+    }
+  }
+}
+
+int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const float* d, int64_t B, int Nc,
+                      int Nf, const float* u, float* z_out, float* pts, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  if (Nc < 3 || Nc > kMaxCoarse || Nf < 1 || Nf > kMaxFine) {
+    set_error("sample_pdf: Nc=%d (3..%d) Nf=%d (1..%d)", Nc, kMaxCoarse, Nf, kMaxFine);
+    return PXO_ERR_ARG;
+  }
+  dim3 grid((unsigned)((B + kRaysPerBlock - 1) / kRaysPerBlock)), block(kRayThreads);
+  hipLaunchKernelGGL(sample_pdf_kernel, grid, block, 0, s, z_c, w_c, o, d, B, Nc, Nf, u, z_out, pts);
+  return check_launch("sample_pdf");
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 uniform generator
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+
+__global__ void uniform_kernel(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi,
+                               float* __restrict__ out) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q * 4 >= n) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t idx = q * 4 + i;
+    if (idx < n) {
+      const float r01 = (float)(c[i] >> 8) * (1.0f / 16777216.0f);   // [0,1), 24 bits
+      out[idx] = lo + (hi - lo) * r01;
+    }
+  }
+}
+
+int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, hipStream_t s) {
+  if (n == 0) return PXO_OK;
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, seed, stream_id, n, lo, hi, out);
+  return check_launch("uniform");
+}
+
+}  // namespace pxo

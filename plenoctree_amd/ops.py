@@ -1,0 +1,280 @@
+"""torch-tensor front end of the C ABI (include/plenoctree_hip.h).
+
+torch is used for device storage and the current HIP stream only; all arithmetic happens in
+libplenoctree_hip.so.  Every tensor must be a contiguous float32 ROCm tensor.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import NET_DEPTH, NET_WIDTH, ENC_PAD, PxoError, check, make_cfg  # noqa: F401
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise PxoError("plenoctree_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous()):
+        raise PxoError("tensor must be a contiguous ROCm tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f(t):
+    if t is not None and t.dtype != torch.float32:
+        raise PxoError(f"expected float32, got {t.dtype}")
+    return _p(t)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _new(*shape, device=None, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def sh_dim(cfg):
+    return (cfg.sh_deg + 1) ** 2
+
+
+def rgb_channels(cfg):
+    return 3 * sh_dim(cfg)
+
+
+def param_layout(cfg):
+    """[(layer, is_bias, offset, rows, cols)] of ONE MLP's sub-arena and its size in floats."""
+    lib = _lib.load()
+    leaves = (_lib.PxoLeaf * _lib.NUM_LEAVES)()
+    n = ctypes.c_int64(0)
+    check(lib.pxo_param_layout(ctypes.byref(cfg), leaves, ctypes.byref(n)), "pxo_param_layout")
+    return [(l.layer, l.is_bias, l.offset, l.rows, l.cols) for l in leaves], n.value
+
+
+def packed_sizes(cfg):
+    lib = _lib.load()
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.pxo_packed_sizes(ctypes.byref(cfg), ctypes.byref(a), ctypes.byref(b)), "pxo_packed_sizes")
+    return a.value, b.value
+
+
+def pack_weights(cfg, mlp_params, packed_fwd=None, packed_bwd=None, need_bwd=True):
+    _require_gpu()
+    lib = _lib.load()
+    nf, nb = packed_sizes(cfg)
+    if packed_fwd is None:
+        packed_fwd = _new(nf, device=mlp_params.device)
+    if need_bwd and packed_bwd is None:
+        packed_bwd = _new(nb, device=mlp_params.device)
+    check(lib.pxo_pack_weights(ctypes.byref(cfg), _f(mlp_params), _f(packed_fwd),
+                               _f(packed_bwd) if need_bwd else None, _stream()), "pxo_pack_weights")
+    return packed_fwd, packed_bwd
+
+
+def sample_along_rays(origins, directions, num_samples, near, far, t_rand=None, lindisp=False):
+    _require_gpu()
+    lib = _lib.load()
+    B = origins.shape[0]
+    z = _new(B, num_samples, device=origins.device)
+    pts = _new(B, num_samples, 3, device=origins.device)
+    check(lib.pxo_sample_along_rays(_f(origins), _f(directions), B, num_samples, near, far, int(lindisp),
+                                    _f(t_rand), _f(z), _f(pts), _stream()), "pxo_sample_along_rays")
+    return z, pts
+
+
+def posenc(x):
+    _require_gpu()
+    lib = _lib.load()
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, 3).contiguous()
+    enc = _new(x2.shape[0], _lib.ENC_DIM, device=x.device)
+    check(lib.pxo_posenc(_f(x2), x2.shape[0], _f(enc), _stream()), "pxo_posenc")
+    return enc.reshape(*lead, _lib.ENC_DIM)
+
+
+def relu_mask_bytes(M):
+    return _lib.load().pxo_relu_mask_bytes(M)
+
+
+def dbias_partial_bytes(M):
+    return _lib.load().pxo_dbias_partial_bytes(M)
+
+
+def mlp_fwd(cfg, packed_fwd, pts, save=False, want_rgb=True):
+    """-> raw_rgb [M,3K] (or None), raw_sigma [M], and if save: (acts [8,M,256], enc [M,64], mask)."""
+    _require_gpu()
+    lib = _lib.load()
+    pts = pts.reshape(-1, 3)
+    M = pts.shape[0]
+    dev = pts.device
+    raw_rgb = _new(M, rgb_channels(cfg), device=dev) if want_rgb else None
+    raw_sigma = _new(M, device=dev)
+    acts = enc = mask = None
+    if save:
+        acts = _new(NET_DEPTH, M, NET_WIDTH, device=dev)
+        enc = _new(M, ENC_PAD, device=dev)
+        mask = _new(max(relu_mask_bytes(M), 16), device=dev, dtype=torch.uint8)
+    check(lib.pxo_mlp_fwd(ctypes.byref(cfg), _f(packed_fwd), _f(pts), M, _f(raw_rgb), _f(raw_sigma),
+                          _f(acts), _f(enc), _p(mask), _stream()), "pxo_mlp_fwd")
+    if save:
+        return raw_rgb, raw_sigma, (acts, enc, mask)
+    return raw_rgb, raw_sigma
+
+
+def mlp_bwd_data(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, mask):
+    _require_gpu()
+    lib = _lib.load()
+    M = d_raw_sigma.shape[0]
+    dev = d_raw_sigma.device
+    dz = _new(NET_DEPTH, M, NET_WIDTH, device=dev)
+    dbias = _new(max(dbias_partial_bytes(M) // 4, 4), device=dev)
+    check(lib.pxo_mlp_bwd_data(ctypes.byref(cfg), _f(packed_bwd), _f(d_raw_rgb), _f(d_raw_sigma), _p(mask), M,
+                               _f(dz), _f(dbias), _stream()), "pxo_mlp_bwd_data")
+    return dz, dbias
+
+
+def mlp_bwd_weights(cfg, acts, enc, dz, d_raw_rgb, d_raw_sigma, dbias):
+    _require_gpu()
+    lib = _lib.load()
+    M = d_raw_sigma.shape[0]
+    dev = d_raw_sigma.device
+    _, n = param_layout(cfg)
+    grads = _new(n, device=dev)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pxo_wgrad_workspace_bytes(ctypes.byref(cfg), M, ctypes.byref(nbytes)), "pxo_wgrad_workspace_bytes")
+    ws = _new(max(nbytes.value, 16), device=dev, dtype=torch.uint8)
+    check(lib.pxo_mlp_bwd_weights(ctypes.byref(cfg), _f(acts), _f(enc), _f(dz), _f(d_raw_rgb), _f(d_raw_sigma),
+                                  _f(dbias), M, _f(grads), _p(ws), nbytes.value, _stream()),
+          "pxo_mlp_bwd_weights")
+    return grads
+
+
+def shade_composite_fwd(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs):
+    _require_gpu()
+    lib = _lib.load()
+    B, S = z_vals.shape
+    dev = z_vals.device
+    comp, disp, acc, w = _new(B, 3, device=dev), _new(B, device=dev), _new(B, device=dev), _new(B, S, device=dev)
+    check(lib.pxo_shade_composite_fwd(ctypes.byref(cfg), _f(raw_rgb), _f(raw_sigma), _f(z_vals), _f(directions),
+                                      _f(viewdirs), B, S, _f(comp), _f(disp), _f(acc), _f(w), _stream()),
+          "pxo_shade_composite_fwd")
+    return comp, disp, acc, w
+
+
+def shade_composite_bwd(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, d_comp_rgb):
+    _require_gpu()
+    lib = _lib.load()
+    B, S = z_vals.shape
+    dev = z_vals.device
+    d_rgb = _new(B * S, rgb_channels(cfg), device=dev)
+    d_sigma = _new(B * S, device=dev)
+    check(lib.pxo_shade_composite_bwd(ctypes.byref(cfg), _f(raw_rgb), _f(raw_sigma), _f(z_vals), _f(directions),
+                                      _f(viewdirs), _f(d_comp_rgb), B, S, _f(d_rgb), _f(d_sigma), _stream()),
+          "pxo_shade_composite_bwd")
+    return d_rgb, d_sigma
+
+
+def sample_pdf(z_coarse, w_coarse, origins, directions, num_fine, u=None):
+    _require_gpu()
+    lib = _lib.load()
+    B, Nc = z_coarse.shape
+    dev = z_coarse.device
+    z = _new(B, Nc + num_fine, device=dev)
+    pts = _new(B, Nc + num_fine, 3, device=dev)
+    check(lib.pxo_sample_pdf(_f(z_coarse), _f(w_coarse), _f(origins), _f(directions), B, Nc, num_fine, _f(u),
+                             _f(z), _f(pts), _stream()), "pxo_sample_pdf")
+    return z, pts
+
+
+def uniform(seed, stream_id, n, lo=0.0, hi=1.0, device=None):
+    _require_gpu()
+    lib = _lib.load()
+    out = _new(n, device=device)
+    check(lib.pxo_uniform(seed, stream_id, n, lo, hi, _f(out), _stream()), "pxo_uniform")
+    return out
+
+
+def adam_step(params, m, v, grads, lr, step, grad_scale=1.0):
+    _require_gpu()
+    lib = _lib.load()
+    check(lib.pxo_adam_step(_f(params), _f(m), _f(v), _f(grads), params.numel(), float(lr), int(step),
+                            float(grad_scale), _stream()), "pxo_adam_step")
+
+
+def render_workspace_bytes(cfg, B):
+    n = ctypes.c_size_t(0)
+    check(_lib.load().pxo_render_workspace_bytes(ctypes.byref(cfg), B, ctypes.byref(n)), "pxo_render_workspace_bytes")
+    return n.value
+
+
+def train_workspace_bytes(cfg, B):
+    n = ctypes.c_size_t(0)
+    check(_lib.load().pxo_train_workspace_bytes(ctypes.byref(cfg), B, ctypes.byref(n)), "pxo_train_workspace_bytes")
+    return n.value
+
+
+def render_fwd(cfg, packed_fwd0, packed_fwd1, origins, directions, viewdirs, randomized=False, t_rand=None, u=None,
+               seed=0, ws=None):
+    """NerfModel.__call__ forward: [(rgb,disp,acc)_coarse, (rgb,disp,acc)_fine]."""
+    _require_gpu()
+    lib = _lib.load()
+    B = origins.shape[0]
+    dev = origins.device
+    nbytes = render_workspace_bytes(cfg, B)
+    if ws is None or ws.numel() < nbytes:
+        ws = _new(max(nbytes, 16), device=dev, dtype=torch.uint8)
+    outs = [(_new(B, 3, device=dev), _new(B, device=dev), _new(B, device=dev))]
+    fine = cfg.num_fine_samples > 0
+    if fine:
+        outs.append((_new(B, 3, device=dev), _new(B, device=dev), _new(B, device=dev)))
+    f = outs[1] if fine else (None, None, None)
+    check(lib.pxo_render_fwd(ctypes.byref(cfg), _f(packed_fwd0), _f(packed_fwd1), _f(origins), _f(directions),
+                             _f(viewdirs), B, int(randomized), _f(t_rand), _f(u), seed, _f(outs[0][0]),
+                             _f(outs[0][1]), _f(outs[0][2]), _f(f[0]), _f(f[1]), _f(f[2]), _p(ws), ws.numel(),
+                             _stream()), "pxo_render_fwd")
+    return outs
+
+
+def train_fwd_bwd(cfg, params, packed, origins, directions, viewdirs, pixels, grads, stats, ws, randomized=True,
+                  t_rand=None, u=None, sp_points=None, seed=0):
+    """loss_fn + value_and_grad on this device's shard; fills grads (2-MLP arena) and stats[6]."""
+    _require_gpu()
+    lib = _lib.load()
+    (f0, b0), (f1, b1) = packed
+    B = origins.shape[0]
+    check(lib.pxo_train_fwd_bwd(ctypes.byref(cfg), _f(params), _f(f0), _f(b0), _f(f1), _f(b1), _f(origins),
+                                _f(directions), _f(viewdirs), _f(pixels), B, int(randomized), _f(t_rand), _f(u),
+                                _f(sp_points), seed, _f(grads), _f(stats), _p(ws), ws.numel(), _stream()),
+          "pxo_train_fwd_bwd")
+
+
+def eval_points(cfg, packed_fwd, points, want_rgb=True):
+    """NerfModel.eval_points_raw: raw_rgb [N,3K] (or None), raw_sigma [N,1]."""
+    _require_gpu()
+    lib = _lib.load()
+    points = points.reshape(-1, 3)
+    N = points.shape[0]
+    dev = points.device
+    raw_rgb = _new(N, rgb_channels(cfg), device=dev) if want_rgb else None
+    raw_sigma = _new(N, 1, device=dev)
+    check(lib.pxo_eval_points(ctypes.byref(cfg), _f(packed_fwd), _f(points), N, _f(raw_rgb), _f(raw_sigma), _stream()),
+          "pxo_eval_points")
+    return raw_rgb, raw_sigma
+
+
+def grid_sigma(cfg, packed_fwd, reso, x0, x1, offset, scale, out=None):
+    """sigma on the dense grid slab x in [x0,x1) (octree/extraction.py:290-320)."""
+    _require_gpu()
+    lib = _lib.load()
+    n = (x1 - x0) * reso * reso
+    if out is None:
+        out = _new(n, device=packed_fwd.device)
+    off = (ctypes.c_float * 3)(*[float(v) for v in offset])
+    sc = (ctypes.c_float * 3)(*[float(v) for v in scale])
+    check(lib.pxo_grid_sigma(ctypes.byref(cfg), _f(packed_fwd), reso, x0, x1, off, sc, _f(out), _stream()),
+          "pxo_grid_sigma")
+    return out

@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: NeRF-SH training rays/sec (800x800 images, 64 coarse + 128 fine samples)
+on N MI355X, BASELINE.json configs[1] (chair-shaped SH16 workload, 4096 rays per GPU per step).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one full train_step (nerf_sh/train.py:51-121) on a synthetic batch: batch sampling,
+weight re-pack, coarse+fine forward, losses (incl. the 10k-point sparsity branch), backward,
+RCCL all-reduce of the 4.05 MB gradient arena (N > 1), Adam.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_FWD_PER_ROW = {3: 1007104, 4: 1020928}          # GEMM MAC x2 per sample
+FLOP_TRAIN_PER_RAY = {3: 756.9e6, 4: 767.6e6}
+PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=4096, help="rays per GPU per step (weak) / global (strong)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--preset", choices=["blender", "tt"], default="blender")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rays", type=int, default=1024, help="rays in the bounded CPU-baseline sample")
+    p.add_argument("--cpu-steps", type=int, default=3)
+    return p.parse_args()
+
+
+def flags_for(preset, batch):
+    from plenoctree_amd.nerf_sh.nerf import utils
+    args = utils.define_flags().parse_args([])
+    args.config = preset
+    utils.update_flags(args)
+    args.dataset = "synthetic"
+    args.batch_size = batch
+    args.factor = 0                       # 800 x 800
+    args.train_dir = "/tmp/pxo_bench"
+    return args
+
+
+def cpu_baseline(args_ns, n_rays, n_steps):
+    """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores
+    on a bounded sample of the same workload: `n_rays` rays x (64+128) samples + 10k sparsity
+    points, forward + backward + Adam, float32, torch CPU threads = all cores."""
+    from oracle import nerf_oracle as O
+    from plenoctree_amd.nerf_sh.nerf import datasets
+    cfg = O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far,
+                sparsity_length=args_ns.sparsity_length, sparsity_radius=args_ns.sparsity_radius)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    flat = O.flatten_params(O.init_params(cfg))
+    m = torch.zeros_like(flat); v = torch.zeros_like(flat)
+    gen = torch.Generator().manual_seed(0)
+    ds = datasets.Synthetic("train", args_ns, torch.device("cpu"), batch_size=n_rays)
+    times = []
+    for step in range(n_steps + 1):
+        batch = next(ds)
+        rays = O.Rays(*batch["rays"])
+        t_rand = torch.rand(n_rays, 64, generator=gen); u = torch.rand(n_rays, 128, generator=gen)
+        sp = (torch.rand(cfg.sparsity_npoints, 3, generator=gen) * 2 - 1) * cfg.sparsity_radius
+        t0 = time.perf_counter()
+        flat, m, v, _, _ = O.train_step(flat, m, v, step, rays, batch["pixels"], cfg, t_rand, u, sp, 5e-4)
+        dt = time.perf_counter() - t0
+        if step > 0:                       # first step warms the allocator / thread pool
+            times.append(dt)
+    rps = n_rays * len(times) / sum(times)
+    return {"value": rps, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} train steps of {n_rays} rays x (64+128) samples + {cfg.sparsity_npoints} "
+                      f"sparsity points, oracle/nerf_oracle.py (torch-CPU f32 restatement, not JAX), "
+                      f"{sum(times):.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+
+    from plenoctree_amd import build, ops
+    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
+    if rank == 0:
+        build.build(verbose=False)
+    if dist:
+        dist.barrier()
+
+    per_gpu = a.batch if a.scaling == "weak" else a.batch // world
+    args = flags_for(a.preset, per_gpu)
+    model, params = models.construct_nerf(args, device)
+    state = models.TrainState(model.cfg, params)
+    dataset = datasets.Synthetic("train", args, device, batch_size=per_gpu, seed=20201473 + rank)
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def one_step(step):
+        batch = next(dataset)
+        lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps)
+        models.train_step(model, state, batch, lr, randomized=True, seed=(step << 8) | rank, world_size=world,
+                          all_reduce=all_reduce if dist else None)
+
+    def sync():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        one_step(s)
+    sync()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for s in range(a.warmup, a.warmup + a.steps):
+        one_step(s)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = state.stats.cpu().tolist()
+
+    # live HIP-event timings of the dominant kernels inside the timed region (this rank)
+    deg = model.cfg.sh_deg
+    names = ["mlp_fwd_kernel", "mlp_bwd_data_kernel", "wgrad_kernel<256,256>", "wgrad_kernel<other>"]
+    # algorithmic FLOP per row: fwd 1.007 MFLOP; bwd(data) = 7 x 2*256*256 + 2*256*(3K+1);
+    # wgrad 256x256 = 2*256*256 per launch-row
+    C1 = 3 * (deg + 1) ** 2 + 1
+    flop_row = [FLOP_FWD_PER_ROW[deg], 7 * 2 * 256 * 256 + 2 * 256 * C1, 2 * 256 * 256, None]
+    kernels = []
+    for tag in range(4):
+        n, ms, rows = ops.profile_read(tag)
+        if n == 0:
+            continue
+        ent = {"kernel": names[tag], "launches": n, "avg_ms": ms / n, "rows_per_launch": rows / n}
+        if flop_row[tag]:
+            ent["tflops"] = rows * flop_row[tag] / (ms * 1e-3) / 1e12
+        kernels.append(ent)
+
+    if rank == 0:
+        total_rays = per_gpu * world * a.steps
+        value = total_rays / elapsed
+        dom = kernels[0] if kernels else None            # mlp_fwd_kernel: largest single launch of the step
+        roofline = None
+        if dom:
+            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                        "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                        "flop_per_launch": dom["rows_per_launch"] * FLOP_FWD_PER_ROW[deg],
+                        "traffic": None}
+        out = {
+            "metric": "training rays/sec (800x800, 64+128 samples)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NeRF-SH {'SH16 blender' if a.preset == 'blender' else 'SH25 tt'} preset, "
+                                   f"{per_gpu} rays/GPU/step x (64 coarse + 128 fine) samples, "
+                                   "800x800 synthetic views, sparsity 10k pts, Adam",
+                       "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
+                       "parallelism": f"dp{world}"},
+            "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            "final_stats": dict(zip(utils.Stats._fields, stats)),
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, a.cpu_rays, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

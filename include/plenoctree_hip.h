@@ -194,6 +194,20 @@ int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* poi
 int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
 
+/* ---- measurement ------------------------------------------------------------------ */
+/* HIP-event timing of the dominant kernels on the stream they are launched on (bench.py's
+ * roofline leg; the reference only has wall-clock rays/sec, nerf_sh/train.py:222-226).
+ * Tags: 0 mlp_fwd, 1 mlp_bwd_data, 2 wgrad 256x256 GEMM, 3 other wgrad GEMMs. */
+#define PXO_PROF_MLP_FWD 0
+#define PXO_PROF_MLP_BWD_DATA 1
+#define PXO_PROF_WGRAD_MAIN 2
+#define PXO_PROF_WGRAD_OTHER 3
+#define PXO_PROF_NUM_TAGS 4
+int pxo_profile_enable(int on);
+/* Synchronises the recorded events and returns launches / total ms / total rows processed
+ * for `tag` since the last read; resets the tag. */
+int pxo_profile_read(int tag, int64_t* launches, double* total_ms, int64_t* total_rows);
+
 #ifdef __cplusplus
 }
 #endif

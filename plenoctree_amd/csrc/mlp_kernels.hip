@@ -312,6 +312,7 @@ static int launch_fwd_nhb(const PxoCfg* cfg, const float* pk, const float* pts, 
                           int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
                           uint32_t* mask, hipStream_t s) {
   dim3 grid_dim((unsigned)num_tiles(M)), block(kFwdThreads);
+  KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
   if (acts)
     hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
                        raw_rgb, raw_sigma, acts, enc, mask);
@@ -429,6 +430,7 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
                         float* dbias_partial, hipStream_t s) {
   if (M == 0) return PXO_OK;
   dim3 grid_dim((unsigned)num_tiles(M)), block(kFwdThreads);
+  KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   switch (head_blocks(cfg->sh_deg)) {
     case 1:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,

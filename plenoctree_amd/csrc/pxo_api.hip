@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "pxo_common.h"
 
@@ -42,8 +43,23 @@ int validate_cfg(const PxoCfg* cfg) {
   return PXO_OK;
 }
 
-int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1, const float* off,
-                        const float* scale, float* sigma_out, hipStream_t s);
+// ---- HIP-event profiler ------------------------------------------------------------------
+struct ProfRecord { hipEvent_t a, b; int tag; int64_t rows; };
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof;
+
+KernelTimer::KernelTimer(int tag, int64_t rows, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  ProfRecord r;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  r.tag = tag; r.rows = rows;
+  hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+KernelTimer::~KernelTimer() {
+  if (slot >= 0) hipEventRecord(g_prof[slot].b, stream);
+}
 
 // bump allocator over the caller's workspace; with base == nullptr it only measures
 struct Carver {
@@ -396,6 +412,30 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   PXO_TRY(launch_sumsq(params, 2 * n_mlp, sc + 3, s));
   PXO_TRY(launch_finalize_stats(sc + 0, sc + 1, sc + 2, sc + 3, B, Nf > 0, t.n_sp, cfg->sparsity_weight, 2 * n_mlp,
                                 stats, s));
+  return PXO_OK;
+}
+
+int pxo_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return PXO_OK;
+}
+
+int pxo_profile_read(int tag, int64_t* launches, double* total_ms, int64_t* total_rows) {
+  PXO_REQUIRE(tag >= 0 && tag < PXO_PROF_NUM_TAGS && launches && total_ms && total_rows, "pxo_profile_read: bad arguments");
+  int64_t n = 0, rows = 0;
+  double ms = 0.0;
+  std::vector<ProfRecord> keep;
+  for (auto& r : g_prof) {
+    if (r.tag != tag) { keep.push_back(r); continue; }
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ++n; ms += t; rows += r.rows;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof.swap(keep);
+  *launches = n; *total_ms = ms; *total_rows = rows;
   return PXO_OK;
 }
 

@@ -98,6 +98,16 @@ int check_launch(const char* what);
 
 int validate_cfg(const PxoCfg* cfg);
 
+// HIP-event bracket around one kernel launch (active only after pxo_profile_enable(1))
+struct KernelTimer {
+  KernelTimer(int tag, int64_t rows, hipStream_t s);
+  ~KernelTimer();
+  int slot;
+  hipStream_t stream;
+};
+int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
+                        const float* off, const float* scale, float* sigma_out, hipStream_t s);
+
 // ---- launchers implemented in the kernel translation units -----------------------------
 int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s);
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,

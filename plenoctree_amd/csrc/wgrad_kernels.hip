@@ -242,8 +242,11 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW);
   // Dense_1..7: h_{l-1}^T dz_l  (for l = 5 these are the first 256 input rows)
   for (int l = 1; l < kDepth; ++l) {
+    {
+    KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
     hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 2, false>), dim3(P), dim3(kWgThreads), 0, s,
                        acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, slab);
+    }
     reduce(kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW);
   }
   // Dense_5 skip rows 256..318: enc^T dz_5

@@ -1,0 +1,170 @@
+"""Ray/pixel feeders for the NeRF-SH trainer.
+
+`Blender` follows the reference's loader (nerf_sh/nerf/datasets.py:189-232: transforms_*.json,
+RGBA composited on white, focal from camera_angle_x) and batch sampler (:149-167: one random
+image, B random pixels with replacement).  `Synthetic` is the stand-in used where no dataset
+exists (the GPU box has none): the same Blender camera convention and sampler over an
+analytic scene whose pixel colours are a closed-form function of the ray, so targets are
+identical for the oracle and the HIP path and PSNR is meaningful."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import utils
+
+
+def pose_spherical(theta_deg, phi_deg, radius):
+    """Blender-convention camera-to-world looking at the origin (-z forward)."""
+    th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
+    eye = radius * np.array([np.cos(ph) * np.sin(th), np.cos(ph) * np.cos(th), np.sin(ph)], np.float64)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up); right /= np.linalg.norm(right)
+    upv = np.cross(right, fwd)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, upv, -fwd, eye
+    return c2w
+
+
+def analytic_scene_rgb(origins, directions, white_bkgd=True):
+    """Colour seen along each ray: three hard spheres with view-dependent shading."""
+    o, d = origins.double(), directions.double()
+    d = d / d.norm(dim=-1, keepdim=True)
+    centers = torch.tensor([[0.0, 0.0, 0.0], [0.7, 0.3, 0.2], [-0.5, -0.4, 0.5]], dtype=torch.float64, device=o.device)
+    radii = torch.tensor([0.6, 0.3, 0.35], dtype=torch.float64, device=o.device)
+    base = torch.tensor([[0.8, 0.3, 0.2], [0.2, 0.7, 0.3], [0.2, 0.3, 0.9]], dtype=torch.float64, device=o.device)
+    best_t = torch.full(o.shape[:-1], float("inf"), dtype=torch.float64, device=o.device)
+    color = torch.ones(*o.shape[:-1], 3, dtype=torch.float64, device=o.device) * (1.0 if white_bkgd else 0.0)
+    for c, r, b in zip(centers, radii, base):
+        oc = o - c
+        bq = (oc * d).sum(-1)
+        disc = bq * bq - ((oc * oc).sum(-1) - r * r)
+        hit = disc > 0
+        t = -bq - torch.sqrt(disc.clamp(min=0))
+        hit = hit & (t > 0) & (t < best_t)
+        n = (o + t[..., None] * d - c) / r
+        diffuse = (0.35 + 0.65 * (n * torch.tensor([0.3, 0.5, 0.8], dtype=torch.float64, device=o.device)).sum(-1).clamp(min=0))
+        spec = (-(n * d).sum(-1)).clamp(min=0) ** 8
+        col = (b * diffuse[..., None] + 0.3 * spec[..., None]).clamp(0, 1)
+        color = torch.where(hit[..., None], col, color)
+        best_t = torch.where(hit, t, best_t)
+    return color.float()
+
+
+class Dataset:
+    """Iterator yielding {"pixels": [B,3], "rays": Rays([B,3] x3)} on `device`."""
+
+    def __init__(self, split, args, device, batch_size=None, seed=20201473):
+        self.split = split
+        self.device = device
+        self.batch_size = batch_size if batch_size is not None else args.batch_size
+        self.white_bkgd = bool(args.white_bkgd)
+        self.rng = np.random.RandomState(seed)      # np.random.seed(20201473 + host_id), train.py:128
+        self.it = 0
+        self._load(args)
+
+    # subclasses set: self.camtoworlds [n,4,4] float32, self.h, self.w, self.focal, self.n_examples
+    def _load(self, args):
+        raise NotImplementedError
+
+    def _pixels_for(self, image_index, ray_indices, rays):
+        raise NotImplementedError
+
+    @property
+    def size(self):
+        return self.n_examples
+
+    def _rays_for(self, image_index, ray_indices):
+        """Rays of the chosen pixels of one image (generate_rays, utils.py:545-589), on device."""
+        c2w = torch.from_numpy(self.camtoworlds[image_index]).to(self.device)
+        idx = ray_indices
+        x = (idx % self.w).float()
+        y = torch.div(idx, self.w, rounding_mode="floor").float()
+        cam = torch.stack([(x - self.w * 0.5) / self.focal, -(y - self.h * 0.5) / self.focal, -torch.ones_like(x)], -1)
+        directions = cam @ c2w[:3, :3].T
+        origins = c2w[:3, 3].expand_as(directions).contiguous()
+        viewdirs = directions / directions.norm(dim=-1, keepdim=True)
+        return utils.Rays(origins, directions.contiguous(), viewdirs.contiguous())
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.split == "train":
+            # datasets.py:159-166: one random image, batch_size random pixels (with replacement)
+            image_index = int(self.rng.randint(0, self.n_examples))
+            ray_indices = torch.from_numpy(self.rng.randint(0, self.h * self.w, (self.batch_size,))).to(self.device)
+            rays = self._rays_for(image_index, ray_indices)
+            return {"pixels": self._pixels_for(image_index, ray_indices, rays), "rays": rays}
+        idx = self.it
+        self.it = (self.it + 1) % self.n_examples
+        return self.get_image(idx)
+
+    def get_image(self, idx):
+        ray_indices = torch.arange(self.h * self.w, device=self.device)
+        rays = self._rays_for(idx, ray_indices)
+        px = self._pixels_for(idx, ray_indices, rays)
+        rs = utils.namedtuple_map(lambda r: r.reshape(self.h, self.w, 3), rays)
+        return {"pixels": px.reshape(self.h, self.w, 3), "rays": rs}
+
+    def peek(self):
+        return self.get_image(self.it) if self.split != "train" else next(self)
+
+
+class Synthetic(Dataset):
+    """100 train / 200 test Blender-convention poses on a sphere of radius 4.0311 around an
+    analytic scene; 800x800, camera_angle_x = 0.6911112."""
+
+    def _load(self, args):
+        n = 100 if self.split == "train" else 200
+        side = 800 if args.factor == 0 else max(800 // args.factor, 8)
+        self.h = self.w = side
+        self.focal = 0.5 * self.w / np.tan(0.5 * 0.6911112)
+        rs = np.random.RandomState(7 if self.split == "train" else 11)
+        self.camtoworlds = np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(n)])
+        self.n_examples = n
+
+    def _pixels_for(self, image_index, ray_indices, rays):
+        return analytic_scene_rgb(rays.origins, rays.directions, self.white_bkgd).contiguous()
+
+
+class Blender(Dataset):
+    """NeRF-Synthetic loader (reference nerf_sh/nerf/datasets.py:189-232)."""
+
+    def _load(self, args):
+        from PIL import Image
+        with open(os.path.join(args.data_dir, f"transforms_{self.split}.json"), "r") as fp:
+            meta = json.load(fp)
+        images, cams = [], []
+        for frame in meta["frames"]:
+            fname = os.path.join(args.data_dir, frame["file_path"] + ".png")
+            img = Image.open(fname)
+            if args.factor >= 2:
+                img = img.resize((img.width // args.factor, img.height // args.factor), Image.BOX)  # area filter
+            image = np.asarray(img, dtype=np.float32) / 255.0
+            cams.append(np.array(frame["transform_matrix"], dtype=np.float32))
+            images.append(image)
+        images = np.stack(images, 0)
+        if self.white_bkgd:
+            images = images[..., :3] * images[..., -1:] + (1.0 - images[..., -1:])   # datasets.py:219-222
+        else:
+            images = images[..., :3]
+        self.h, self.w = images.shape[1:3]
+        self.camtoworlds = np.stack(cams, 0)
+        self.focal = 0.5 * self.w / np.tan(0.5 * float(meta["camera_angle_x"]))      # :226-228
+        self.n_examples = images.shape[0]
+        self.images = torch.from_numpy(images.reshape(self.n_examples, -1, 3))       # host; gathered per batch
+
+    def _pixels_for(self, image_index, ray_indices, rays):
+        return self.images[image_index][ray_indices.cpu()].to(self.device).contiguous()
+
+
+dataset_dict = {"blender": Blender, "synthetic": Synthetic}
+
+
+def get_dataset(split, args, device, batch_size=None):
+    if args.dataset not in dataset_dict:
+        raise NotImplementedError(f"dataset {args.dataset} is not built on the MI355X path")
+    return dataset_dict[args.dataset](split, args, device, batch_size=batch_size)

@@ -278,3 +278,14 @@ def grid_sigma(cfg, packed_fwd, reso, x0, x1, offset, scale, out=None):
     check(lib.pxo_grid_sigma(ctypes.byref(cfg), _f(packed_fwd), reso, x0, x1, off, sc, _f(out), _stream()),
           "pxo_grid_sigma")
     return out
+
+
+def profile_enable(on=True):
+    check(_lib.load().pxo_profile_enable(int(on)), "pxo_profile_enable")
+
+
+def profile_read(tag):
+    """(launches, total_ms, total_rows) of the kernels tagged `tag` since the last read."""
+    n, ms, rows = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(_lib.load().pxo_profile_read(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(rows)), "pxo_profile_read")
+    return n.value, ms.value, rows.value

@@ -96,6 +96,11 @@ def load(path=None):
     if _lib is not None:
         return _lib
     path = path or LIB_PATH
+    # torch must load (and initialise) its HIP runtime first: the library then binds to the same
+    # libamdhip64 instance, so device pointers and streams are shared with torch.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     if not os.path.exists(path):
         raise PxoError(
             f"{path} not found: build it with `python -m plenoctree_amd.build` "

@@ -141,11 +141,12 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, int64_t n, float lr, float bc1, float bc2,
                             float grad_scale) {
-  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  // (1. - beta) is a python double in flax, rounded to f32 when it meets the f32 gradient
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * (gi * gi);
     m[i] = mi;
     v[i] = vi;
     const float mhat = mi / bc1, vhat = vi / bc2;

@@ -249,6 +249,7 @@ size_t pxo_dbias_partial_bytes(int64_t M) { return (size_t)dbias_floats(M) * siz
 int pxo_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M, float* raw_rgb,
                 float* raw_sigma, float* acts, float* enc, void* relu_mask, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (M == 0) return PXO_OK;
   PXO_REQUIRE(M >= 0 && packed_fwd && pts && raw_sigma, "pxo_mlp_fwd: bad arguments");
   PXO_REQUIRE((acts != nullptr) == (enc != nullptr) && (acts != nullptr) == (relu_mask != nullptr),
               "pxo_mlp_fwd: acts, enc and relu_mask must be all set or all NULL");
@@ -259,6 +260,7 @@ int pxo_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, in
 int pxo_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
                      const void* relu_mask, int64_t M, float* dz, float* dbias_partial, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (M == 0) return PXO_OK;
   PXO_REQUIRE(M >= 0 && packed_bwd && d_raw_rgb && d_raw_sigma && relu_mask && dz && dbias_partial,
               "pxo_mlp_bwd_data: bad arguments");
   return launch_mlp_bwd_data(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, (const uint32_t*)relu_mask, M, dz,
@@ -442,6 +444,7 @@ int pxo_profile_read(int tag, int64_t* launches, double* total_ms, int64_t* tota
 int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* points, int64_t N, float* raw_rgb,
                     float* raw_sigma, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (N == 0) return PXO_OK;
   PXO_REQUIRE(N >= 0 && packed_fwd && points && raw_sigma, "pxo_eval_points: bad arguments");
   return launch_mlp_fwd(cfg, packed_fwd, points, N, raw_rgb, raw_sigma, nullptr, nullptr, nullptr,
                         (hipStream_t)stream);

@@ -145,10 +145,11 @@ __device__ __forceinline__ void grid_point(const GridSpec& g, int64_t n, float& 
 }
 
 // writes posenc of the tile's 128 points into lds[:, 0:64]
+template <int NT>
 __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float* __restrict__ pts,
                                             const GridSpec& grid, int64_t row0, int64_t M, int tid) {
-  constexpr int kParts = kFwdThreads / kTM;       // 2
-  constexpr int kColsPer = kEncPad / kParts;      // 32
+  constexpr int kParts = NT / kTM;                // 2 or 4
+  constexpr int kColsPer = kEncPad / kParts;      // 32 or 16
   const int row = tid % kTM, part = tid / kTM;
   const int64_t grow = row0 + row;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -212,24 +213,28 @@ __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int NHB, bool SAVE>
-__global__ __launch_bounds__(kFwdThreads, 1) void mlp_fwd_kernel(
+// NW = waves per workgroup: 4 (one per SIMD, each 128 rows x 64 cols) or 8 (two per SIMD, each
+// 128 rows x 32 cols; the second wave's MFMAs cover the first one's waits and epilogues).
+template <int NHB, bool SAVE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_fwd_kernel(
     const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma, float* __restrict__ acts,
     float* __restrict__ enc_out, uint32_t* __restrict__ mask) {
+  constexpr int NT = NW * 64, CPW = 8 / NW, MW = 4 * CPW * 16 / 32;
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row0 = tile * kTM;
+  const bool full = row0 + kTM <= M;
   const int C = rgb_channels(deg);
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
 
-  posenc_tile(lds, pts, grid, row0, M, tid);
+  posenc_tile<NT>(lds, pts, grid, row0, M, tid);
   __syncthreads();
   if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
 #pragma unroll
-    for (int i = 0; i < kTM * kEncPad / 4 / kFwdThreads; ++i) {
-      const int idx = tid + kFwdThreads * i;
+    for (int i = 0; i < kTM * kEncPad / 4 / NT; ++i) {
+      const int idx = tid + NT * i;
       const int row = idx >> 4, c4 = idx & 15;
       if (row0 + row < M)
         *reinterpret_cast<f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4) =
@@ -238,29 +243,29 @@ __global__ __launch_bounds__(kFwdThreads, 1) void mlp_fwd_kernel(
   }
 
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  f32x16 acc[4][kCPW];
+  f32x16 acc[4][CPW];
   for (int l = 0; l < kDepth; ++l) {
     zero_acc(acc);
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCPW) * 64 + lane;
-    gemm_lds_packed<4, kCPW>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * CPW) * 64 + lane;
+    gemm_lds_packed<4, CPW>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
     if (l == 5) {
       // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
       // columns are a second K segment; the encoding is recomputed into the consumed tile.
       __syncthreads();
-      posenc_tile(lds, pts, grid, row0, M, tid);
+      posenc_tile<NT>(lds, pts, grid, row0, M, tid);
       __syncthreads();
-      gemm_lds_packed<4, kCPW>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
+      gemm_lds_packed<4, CPW>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
     }
     __syncthreads();  // every wave has consumed the input tile
-    uint32_t mw[kMaskWords];
+    uint32_t mw[MW];
 #pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) mw[w] = 0u;
-    float* __restrict__ act_l = SAVE ? acts + (int64_t)l * M * kW : nullptr;
+    for (int w = 0; w < MW; ++w) mw[w] = 0u;
+    float* __restrict__ act_l = SAVE ? acts + (int64_t)l * M * kW + row0 * kW : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < kCPW; ++c) {
-        const int col = (wave * kCPW + c) * 32 + (lane & 31);
+      for (int c = 0; c < CPW; ++c) {
+        const int col = (wave * CPW + c) * 32 + (lane & 31);
         const float b = bias[l * kW + col];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -268,57 +273,90 @@ __global__ __launch_bounds__(kFwdThreads, 1) void mlp_fwd_kernel(
           const float v = fmaxf(acc[r][c][reg] + b, 0.f);
           lds[row * kLDA + col] = v;
           if (SAVE) {
-            const int bit = (r * kCPW + c) * 16 + reg;
+            const int bit = (r * CPW + c) * 16 + reg;
             if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
-            if (row0 + row < M) act_l[(row0 + row) * kW + col] = v;
+            if (full || row0 + row < M) act_l[row * kW + col] = v;
           }
         }
       }
     if (SAVE) {
-      uint32_t* mp = mask + ((tile * kDepth + l) * kFwdThreads + tid) * kMaskWords;
+      uint32_t* mp = mask + ((tile * kDepth + l) * NT + tid) * MW;
 #pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) mp[w] = mw[w];
+      for (int w = 0; w < MW; ++w) mp[w] = mw[w];
     }
     __syncthreads();
   }
 
   // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
-  // wave w owns rows 32w..32w+31 and all NHB column blocks.
+  // wave w owns row block w%4 and the column blocks (w/4), (w/4)+NW/4, ...
   {
-    f32x16 hacc[1][NHB];
-    zero_acc(hacc);
+    constexpr int CSTEP = NW / 4;                       // 1 or 2
+    constexpr int HMAX = (NHB + CSTEP - 1) / CSTEP;     // column blocks per wave (upper bound)
+    const int rb = wave & 3, cb0 = wave >> 2;
+    f32x16 hacc[HMAX];
+#pragma unroll
+    for (int i = 0; i < HMAX; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) hacc[i][e] = 0.f;
     const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + lane;
-    gemm_lds_packed<1, NHB>(arow + wave * 32 * kLDA, wp, 32, NHB * 64, hacc);
+    const float* ar = arow + rb * 32 * kLDA;
+    for (int g = 0; g < 32; ++g) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + g * 8);
+#pragma unroll
+      for (int i = 0; i < HMAX; ++i) {
+        const int cb = cb0 + i * CSTEP;
+        if (cb < NHB) {
+          const f32x4 b = wp[((int64_t)g * NHB + cb) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], hacc[i], 0, 0, 0);
+        }
+      }
+    }
     const float* hb = bias + 8 * kW;
 #pragma unroll
-    for (int c = 0; c < NHB; ++c) {
-      const int col = c * 32 + (lane & 31);
-      const float b = hb[col];
+    for (int i = 0; i < HMAX; ++i) {
+      const int cb = cb0 + i * CSTEP;
+      if (cb < NHB) {
+        const int col = cb * 32 + (lane & 31);
+        const float b = hb[col];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t grow = row0 + wave * 32 + frag_row(reg, lane);
-        if (grow < M) {
-          const float v = hacc[0][c][reg] + b;
-          if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
-          else if (col == C) raw_sigma[grow] = v;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
+          if (grow < M) {
+            const float v = hacc[i][reg] + b;
+            if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
+            else if (col == C) raw_sigma[grow] = v;
+          }
         }
       }
     }
   }
 }
 
+int g_mlp_waves = 4;   // pxo_set_option("mlp_waves", 4|8)
+
+template <int NHB, int NW>
+static void launch_fwd_nw(const float* pk, const float* pts, const GridSpec& grid, int64_t M, int deg,
+                          float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
+                          hipStream_t s) {
+  dim3 grid_dim((unsigned)num_tiles(M)), block(NW * 64);
+  if (acts)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, NW>), grid_dim, block, 0, s, pk, pts, grid, M, deg,
+                       raw_rgb, raw_sigma, acts, enc, mask);
+  else
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, NW>), grid_dim, block, 0, s, pk, pts, grid, M, deg,
+                       raw_rgb, raw_sigma, acts, enc, mask);
+}
+
 template <int NHB>
 static int launch_fwd_nhb(const PxoCfg* cfg, const float* pk, const float* pts, const GridSpec& grid,
                           int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
                           uint32_t* mask, hipStream_t s) {
-  dim3 grid_dim((unsigned)num_tiles(M)), block(kFwdThreads);
   KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
-  if (acts)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+  if (g_mlp_waves == 8)
+    launch_fwd_nw<NHB, 8>(pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma, acts, enc, mask, s);
   else
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+    launch_fwd_nw<NHB, 4>(pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma, acts, enc, mask, s);
   return check_launch("mlp_fwd");
 }
 
@@ -354,20 +392,22 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // ------------------------------------------------------------------------------------------
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
-template <int NHB>
-__global__ __launch_bounds__(kFwdThreads, 1) void mlp_bwd_data_kernel(
+template <int NHB, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg,
     float* __restrict__ dz, float* __restrict__ dbias_partial) {
+  constexpr int NT = NW * 64, CPW = 8 / NW, MW = 4 * CPW * 16 / 32;
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
   constexpr int NH = 32 * NHB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row0 = tile * kTM;
+  const bool full = row0 + kTM <= M;
   const int C = rgb_channels(deg);
 
   // d_raw tile -> lds[:, 0:NH] with the head's column order
-  for (int idx = tid; idx < kTM * NH; idx += kFwdThreads) {
+  for (int idx = tid; idx < kTM * NH; idx += NT) {
     const int row = idx / NH, col = idx - row * NH;
     const int64_t grow = row0 + row;
     float v = 0.f;
@@ -385,32 +425,32 @@ __global__ __launch_bounds__(kFwdThreads, 1) void mlp_bwd_data_kernel(
   }
 
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  f32x16 acc[4][kCPW];
+  f32x16 acc[4][CPW];
   zero_acc(acc);
   {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCPW) * 64 + lane;
-    gemm_lds_packed<4, kCPW>(arow, wp, 4 * NHB, 8 * 64, acc);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * CPW) * 64 + lane;
+    gemm_lds_packed<4, CPW>(arow, wp, 4 * NHB, 8 * 64, acc);
   }
   for (int l = kDepth - 1; l >= 0; --l) {
-    uint32_t mw[kMaskWords];
-    const uint32_t* mp = mask + ((tile * kDepth + l) * kFwdThreads + tid) * kMaskWords;
+    uint32_t mw[MW];
+    const uint32_t* mp = mask + ((tile * kDepth + l) * NT + tid) * MW;
 #pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
+    for (int w = 0; w < MW; ++w) mw[w] = mp[w];
     __syncthreads();  // previous GEMM has consumed the tile
-    float* __restrict__ dz_l = dz + (int64_t)l * M * kW;
+    float* __restrict__ dz_l = dz + (int64_t)l * M * kW + row0 * kW;
 #pragma unroll
-    for (int c = 0; c < kCPW; ++c) {
-      const int col = (wave * kCPW + c) * 32 + (lane & 31);
+    for (int c = 0; c < CPW; ++c) {
+      const int col = (wave * CPW + c) * 32 + (lane & 31);
       float colsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = r * 32 + frag_row(reg, lane);
-          const int bit = (r * kCPW + c) * 16 + reg;
+          const int bit = (r * CPW + c) * 16 + reg;
           const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
           lds[row * kLDA + col] = v;
-          if (row0 + row < M) dz_l[(row0 + row) * kW + col] = v;
+          if (full || row0 + row < M) dz_l[row * kW + col] = v;
           colsum += v;
         }
       colsum += __shfl_xor(colsum, 32);
@@ -419,31 +459,34 @@ __global__ __launch_bounds__(kFwdThreads, 1) void mlp_bwd_data_kernel(
     __syncthreads();
     if (l > 0) {
       zero_acc(acc);
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCPW) * 64 + lane;
-      gemm_lds_packed<4, kCPW>(arow, wp, 32, 8 * 64, acc);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * CPW) * 64 + lane;
+      gemm_lds_packed<4, CPW>(arow, wp, 32, 8 * 64, acc);
     }
   }
+}
+
+template <int NHB>
+static void launch_bwd_nhb(const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
+                           const uint32_t* mask, int64_t M, int deg, float* dz, float* dbias_partial,
+                           hipStream_t s) {
+  dim3 grid_dim((unsigned)num_tiles(M));
+  if (g_mlp_waves == 8)
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB, 8>), grid_dim, dim3(512), 0, s, packed_bwd, d_raw_rgb,
+                       d_raw_sigma, mask, M, deg, dz, dbias_partial);
+  else
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB, 4>), grid_dim, dim3(256), 0, s, packed_bwd, d_raw_rgb,
+                       d_raw_sigma, mask, M, deg, dz, dbias_partial);
 }
 
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
                         float* dbias_partial, hipStream_t s) {
   if (M == 0) return PXO_OK;
-  dim3 grid_dim((unsigned)num_tiles(M)), block(kFwdThreads);
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   switch (head_blocks(cfg->sh_deg)) {
-    case 1:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
-      break;
-    case 2:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<2>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
-      break;
-    default:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<3>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
-      break;
+    case 1: launch_bwd_nhb<1>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
+    case 2: launch_bwd_nhb<2>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
+    default: launch_bwd_nhb<3>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
   }
   return check_launch("mlp_bwd_data");
 }

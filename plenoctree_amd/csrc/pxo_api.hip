@@ -417,6 +417,17 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   return PXO_OK;
 }
 
+int pxo_set_option(const char* name, int value) {
+  PXO_REQUIRE(name != nullptr, "pxo_set_option: NULL name");
+  if (strcmp(name, "mlp_waves") == 0) {
+    PXO_REQUIRE(value == 4 || value == 8, "mlp_waves must be 4 or 8 (got %d)", value);
+    g_mlp_waves = value;
+    return PXO_OK;
+  }
+  set_error("pxo_set_option: unknown option %s", name);
+  return PXO_ERR_ARG;
+}
+
 int pxo_profile_enable(int on) {
   g_prof_on = on != 0;
   return PXO_OK;

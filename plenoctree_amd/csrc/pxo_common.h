@@ -97,6 +97,7 @@ int check_launch(const char* what);
   } while (0)
 
 int validate_cfg(const PxoCfg* cfg);
+extern int g_mlp_waves;   // 4 or 8 waves per workgroup in the fused MLP kernels
 
 // HIP-event bracket around one kernel launch (active only after pxo_profile_enable(1))
 struct KernelTimer {

@@ -195,7 +195,7 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
 
 /* Tuning knobs (speed only, results unchanged up to float32 summation order):
- *   "mlp_waves" = 4 | 8   waves per workgroup of the fused MLP kernels (default 4).
+ *   "mlp_waves" = 4 | 8   waves per workgroup of the fused MLP kernels (default 8).
  * The relu_mask image of pxo_mlp_fwd is only valid for pxo_mlp_bwd_data under the same value. */
 int pxo_set_option(const char* name, int value);
 

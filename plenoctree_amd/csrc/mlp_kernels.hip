@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_fwd_kernel(
   }
 }
 
-int g_mlp_waves = 4;   // pxo_set_option("mlp_waves", 4|8)
+int g_mlp_waves = 8;   // pxo_set_option("mlp_waves", 4|8)
 
 template <int NHB, int NW>
 static void launch_fwd_nw(const float* pk, const float* pts, const GridSpec& grid, int64_t M, int deg,

@@ -80,6 +80,7 @@ def define_flags(parser=None):
     a("--eval_once", type=_bool, default=True)
     a("--save_output", type=_bool, default=True)
     a("--chunk", type=int, default=8192)
+    a("--approx_eval_skip", type=int, default=1)     # evaluate only every x images (utils.py:225-229)
     a("--seed", type=int, default=20200823)
     return p
 

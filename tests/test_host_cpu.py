@@ -1,0 +1,123 @@
+"""Host-side logic of the reference-mirroring layer (flags, presets, schedules, feeders,
+checkpoints) -- runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from plenoctree_amd.nerf_sh.nerf import checkpoints, datasets, utils
+
+
+def _args(argv=()):
+    return utils.define_flags().parse_args(list(argv))
+
+
+def test_presets_and_flag_errors(tmp_path):
+    a = _args(["--config", "blender", "--train_dir", "x"])
+    utils.update_flags(a)
+    assert (a.sh_deg, a.num_coarse_samples, a.num_fine_samples, a.use_viewdirs, a.batch_size) == (3, 64, 128, False, 1024)
+    a = _args(["--config", "tt", "--train_dir", "x"])
+    utils.update_flags(a)
+    assert (a.sh_deg, a.near, a.far, a.sparsity_radius, a.sparsity_length) == (4, 0.0, 4.0, 5.0, 0.2)
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("not_a_flag: 1\n")
+    a = _args(["--config", str(bad)])
+    with pytest.raises(ValueError):            # nerf_sh/nerf/utils.py:241-243
+        utils.update_flags(a)
+    with pytest.raises(ValueError):            # train_dir must be set (:248-249)
+        utils.check_flags(_args([]))
+    a = _args(["--train_dir", "x", "--data_dir", "y"])   # defaults: use_viewdirs=True, sh_deg=-1
+    with pytest.raises(NotImplementedError):
+        utils.check_flags(a)
+    a = _args(["--config", "blender", "--train_dir", "x", "--data_dir", "y", "--batch_size", "1000"])
+    utils.update_flags(a); a.batch_size = 1001
+    with pytest.raises(ValueError):            # batch divisible by device count (:252)
+        utils.check_flags(a, require_batch_size_div=True, world_size=8)
+
+
+def test_lr_psnr_rays_match_oracle():
+    for step in (0, 1, 500, 999999, 2000000, 3000000):
+        assert utils.learning_rate_decay(step, 5e-4, 5e-6, 2000000) == pytest.approx(
+            O.learning_rate_decay(step, 5e-4, 5e-6, 2000000), rel=1e-12)
+    assert utils.learning_rate_decay(10, 5e-4, 5e-6, 1000, 100, 0.01) == pytest.approx(
+        O.learning_rate_decay(10, 5e-4, 5e-6, 1000, 100, 0.01), rel=1e-12)
+    assert utils.compute_psnr(1e-3) == pytest.approx(30.0)
+    c2w = np.stack([datasets.pose_spherical(30.0, 20.0, 4.0311), datasets.pose_spherical(200.0, -5.0, 4.0311)])
+    r1, r2 = utils.generate_rays(9, 7, 12.0, c2w), O.generate_rays(9, 7, 12.0, c2w)
+    for a, b in zip(r1, r2):
+        np.testing.assert_array_equal(a, b)
+    # cameras look at the origin along -z
+    for m in c2w:
+        fwd = -m[:3, 2]
+        np.testing.assert_allclose(fwd, -m[:3, 3] / np.linalg.norm(m[:3, 3]), atol=1e-6)
+
+
+def test_synthetic_dataset_batches():
+    a = _args(["--config", "blender", "--train_dir", "x", "--dataset", "synthetic"])
+    utils.update_flags(a); a.dataset = "synthetic"; a.factor = 8
+    ds = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=64)
+    assert ds.h == ds.w == 100 and ds.size == 100
+    b = next(ds)
+    assert b["pixels"].shape == (64, 3) and b["rays"].origins.shape == (64, 3)
+    assert float(b["pixels"].min()) >= 0 and float(b["pixels"].max()) <= 1
+    np.testing.assert_allclose(b["rays"].viewdirs.norm(dim=-1).numpy(), 1.0, rtol=1e-5)
+    # per-pixel rays agree with generate_rays (nerf_sh/nerf/utils.py:545-589)
+    img = datasets.get_dataset("test", a, torch.device("cpu")).get_image(3)
+    ds_t = datasets.get_dataset("test", a, torch.device("cpu"))
+    ref = utils.generate_rays(ds_t.w, ds_t.h, ds_t.focal, ds_t.camtoworlds[3:4])
+    np.testing.assert_allclose(img["rays"].directions.numpy(), ref.directions[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(img["rays"].origins.numpy(), ref.origins[0], rtol=1e-6)
+    # same seed -> same batch sequence (np.random.seed(20201473 + host_id), train.py:128)
+    d1 = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=8)
+    d2 = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=8)
+    assert torch.equal(next(d1)["pixels"], next(d2)["pixels"])
+    with pytest.raises(NotImplementedError):
+        a.dataset = "llff"
+        datasets.get_dataset("train", a, torch.device("cpu"))
+
+
+def test_blender_loader(tmp_path):
+    from PIL import Image
+    import json
+    frames = []
+    os.makedirs(tmp_path / "train")
+    for i in range(3):
+        rgba = (np.random.RandomState(i).rand(8, 8, 4) * 255).astype(np.uint8)
+        Image.fromarray(rgba, "RGBA").save(tmp_path / "train" / f"r_{i}.png")
+        frames.append({"file_path": f"./train/r_{i}", "transform_matrix": datasets.pose_spherical(40 * i, 30, 4).tolist()})
+    (tmp_path / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911112, "frames": frames}))
+    a = _args(["--config", "blender", "--train_dir", "x", "--data_dir", str(tmp_path)])
+    utils.update_flags(a)
+    ds = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=16)
+    assert (ds.h, ds.w, ds.size) == (8, 8, 3)
+    assert ds.focal == pytest.approx(0.5 * 8 / np.tan(0.5 * 0.6911112))
+    rgba = np.asarray(Image.open(tmp_path / "train" / "r_1.png"), np.float32) / 255
+    want = rgba[..., :3] * rgba[..., 3:] + (1 - rgba[..., 3:])           # white background composite
+    np.testing.assert_allclose(ds.images[1].numpy().reshape(8, 8, 3), want, rtol=1e-6)
+    b = next(ds)
+    assert b["pixels"].shape == (16, 3)
+
+
+class _FakeState:
+    def __init__(self):
+        self.params = torch.arange(5.0); self.m = torch.zeros(5); self.v = torch.ones(5); self.step = 7
+
+    def state_dict(self):
+        return {"params": self.params, "m": self.m, "v": self.v, "step": self.step}
+
+    def load_state_dict(self, sd):
+        self.params, self.m, self.v, self.step = sd["params"], sd["m"], sd["v"], int(sd["step"])
+
+
+def test_checkpoint_roundtrip_and_keep(tmp_path):
+    st = _FakeState()
+    assert checkpoints.restore_checkpoint(str(tmp_path), st) is None
+    for step in (10, 20, 30):
+        st.step = step; st.params = st.params + 1
+        checkpoints.save_checkpoint(str(tmp_path), st, step, keep=2)
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint_20", "checkpoint_30"]
+    fresh = _FakeState()
+    assert checkpoints.restore_checkpoint(str(tmp_path), fresh).endswith("checkpoint_30")
+    assert fresh.step == 30 and torch.equal(fresh.params, st.params)

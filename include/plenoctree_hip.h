@@ -39,7 +39,7 @@ extern "C" {
 #define PXO_SKIP_LAYER 4
 #define PXO_ENC_DIM 63      /* 3*(1+2*10), nerf_sh/nerf/model_utils.py:145-173 */
 #define PXO_ENC_PAD 64
-#define PXO_TILE_ROWS 128   /* rows (samples) per workgroup in the fused MLP kernels */
+#define PXO_TILE_ROWS 64    /* rows (samples) per tile in the fused MLP kernels */
 #define PXO_NUM_LEAVES 20   /* per MLP: 10 x (kernel, bias) */
 
 /* Hyper-parameters of the path: the flags of nerf_sh/nerf/utils.py:61-230 that reach the
@@ -193,11 +193,6 @@ int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* poi
  * all y,z (ij meshgrid order, x slowest).  sigma_out [(x1-x0)*reso*reso]. */
 int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
-
-/* Tuning knobs (speed only, results unchanged up to float32 summation order):
- *   "mlp_waves" = 4 | 8   waves per workgroup of the fused MLP kernels (default 8).
- * The relu_mask image of pxo_mlp_fwd is only valid for pxo_mlp_bwd_data under the same value. */
-int pxo_set_option(const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing of the dominant kernels on the stream they are launched on (bench.py's

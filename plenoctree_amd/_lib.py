@@ -15,7 +15,7 @@ NET_DEPTH = 8
 NET_WIDTH = 256
 ENC_DIM = 63
 ENC_PAD = 64
-TILE_ROWS = 128
+TILE_ROWS = 64
 NUM_LEAVES = 20
 
 
@@ -82,7 +82,6 @@ SIGNATURES = {
     "pxo_train_fwd_bwd": (c_int, [CFG, P, P, P, P, P, P, P, P, P, c_int64, c_int, P, P, P, c_uint64, P, P,
                                   P, c_size_t, P]),
     "pxo_eval_points": (c_int, [CFG, P, P, c_int64, P, P, P]),
-    "pxo_set_option": (c_int, [c_char_p, c_int]),
     "pxo_profile_enable": (c_int, [c_int]),
     "pxo_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "pxo_grid_sigma": (c_int, [CFG, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P]),
@@ -112,9 +111,6 @@ def load(path=None):
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
-    waves = os.environ.get("PXO_MLP_WAVES")
-    if waves:
-        check(lib.pxo_set_option(b"mlp_waves", int(waves)), "pxo_set_option(mlp_waves)")
     return lib
 
 

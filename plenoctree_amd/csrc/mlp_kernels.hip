@@ -5,15 +5,19 @@
 // SH configuration (nerf_sh/config/blender.yaml, tt.yaml), plus its reverse-mode data path.
 //
 // Design (exact f32, v_mfma_f32_32x32x2_f32):
-//  * one workgroup = 128 samples; the 128x256 activation tile lives in LDS (row stride 260
-//    floats: conflict-free ds_read_b128 A-fragments) for all 8 layers and is updated in place;
+//  * persistent workgroups (two per CU, 4 waves each) walk 64-sample tiles; the 64x256 activation
+//    tile lives in LDS (row stride 260 floats: conflict-free ds_read_b128 A-fragments) for all 8
+//    layers and is updated in place.  Two independent workgroups per CU mean one's epilogue /
+//    barriers overlap the other's MFMAs on the same SIMDs;
 //  * weights are pre-packed in MFMA fragment order (pxo_common.h packed_index) so the B operand
 //    is one coalesced 16 B/lane load straight from L2 into registers -- each wave owns a
 //    disjoint 64-column slice of the layer, so weights need no LDS staging at all;
 //  * the K order inside a dot product is permuted (lane half h, sub-step j -> k = 8g+4h+j) so
 //    that one ds_read_b128 / one 16 B global load feeds four consecutive MFMAs;
-//  * post-ReLU activations are streamed to HBM once (for the weight-gradient GEMMs) together
-//    with a 1-bit relu mask in fragment order, so the backward-data kernel never re-reads them.
+//  * post-ReLU activations are streamed to HBM once (for the weight-gradient GEMMs) as whole
+//    1 KiB rows copied out of the LDS tile, together with a 1-bit relu mask in fragment order, so
+//    the backward-data kernel never re-reads them; bias gradients accumulate in registers across
+//    a workgroup's tiles.
 #include "pxo_common.h"
 
 namespace pxo {
@@ -144,12 +148,11 @@ __device__ __forceinline__ void grid_point(const GridSpec& g, int64_t n, float& 
   pz = ((((float)iz + 0.5f) / (float)r) - g.off[2]) / g.scale[2];
 }
 
-// writes posenc of the tile's 128 points into lds[:, 0:64]
-template <int NT>
+// writes posenc of the tile's kTM points into lds[:, 0:64]
 __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float* __restrict__ pts,
                                             const GridSpec& grid, int64_t row0, int64_t M, int tid) {
-  constexpr int kParts = NT / kTM;                // 2 or 4
-  constexpr int kColsPer = kEncPad / kParts;      // 32 or 16
+  constexpr int kParts = kMlpThreads / kTM;       // 4
+  constexpr int kColsPer = kEncPad / kParts;      // 16
   const int row = tid % kTM, part = tid / kTM;
   const int64_t grow = row0 + row;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -165,35 +168,40 @@ __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// the 128-row x (CBN*32)-col wave GEMM: A from LDS (ds_read_b128), B from the packed image
+// the (RBN*32)-row x (CBN*32)-col wave GEMM: A from LDS (ds_read_b128), B from the packed image.
+// kgroups must be even; operands are ping-ponged between two register sets (no copies).
 // ------------------------------------------------------------------------------------------
 template <int RBN, int CBN>
-__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow,
-                                                const f32x4* __restrict__ wp, int kgroups,
-                                                int kg_stride, f32x16 (&acc)[RBN][CBN]) {
-  f32x4 a[RBN], b[CBN];
+__device__ __forceinline__ void mfma_group(const f32x4 (&a)[RBN], const f32x4 (&b)[CBN], f32x16 (&acc)[RBN][CBN]) {
 #pragma unroll
-  for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA);
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int c = 0; c < CBN; ++c) b[c] = wp[c * 64];
-  for (int g = 0; g < kgroups; ++g) {
-    const int gn = (g + 1 < kgroups) ? g + 1 : g;
-    f32x4 an[RBN], bn[CBN];
+    for (int r = 0; r < RBN; ++r)
 #pragma unroll
-    for (int c = 0; c < CBN; ++c) bn[c] = wp[(int64_t)gn * kg_stride + c * 64];
+      for (int c = 0; c < CBN; ++c)
+        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
+}
+
+template <int RBN, int CBN>
+__device__ __forceinline__ void load_group(const float* __restrict__ arow, const f32x4* __restrict__ wp, int g,
+                                           int kg_stride, f32x4 (&a)[RBN], f32x4 (&b)[CBN]) {
 #pragma unroll
-    for (int r = 0; r < RBN; ++r) an[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + gn * 8);
+  for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < RBN; ++r)
-#pragma unroll
-        for (int c = 0; c < CBN; ++c)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < RBN; ++r) a[r] = an[r];
-#pragma unroll
-    for (int c = 0; c < CBN; ++c) b[c] = bn[c];
+  for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + g * 8);
+}
+
+template <int RBN, int CBN>
+__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
+  f32x4 a0[RBN], b0[CBN], a1[RBN], b1[CBN];
+  load_group<RBN, CBN>(arow, wp, 0, kg_stride, a0, b0);
+  for (int g = 0; g < kgroups; g += 2) {
+    load_group<RBN, CBN>(arow, wp, g + 1, kg_stride, a1, b1);
+    mfma_group<RBN, CBN>(a0, b0, acc);
+    const int gn = g + 2 < kgroups ? g + 2 : g;      // harmless re-load on the last trip
+    load_group<RBN, CBN>(arow, wp, gn, kg_stride, a0, b0);
+    mfma_group<RBN, CBN>(a1, b1, acc);
   }
 }
 
@@ -210,122 +218,137 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {
 // accumulator register `reg` of a 32x32 tile holds row (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// coalesced copy of the finished kTM x 256 LDS tile to a row-major [M,256] global array
+__device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
+                                           int64_t M, bool full, int tid) {
+#pragma unroll
+  for (int i = 0; i < kTM * kW / 4 / kMlpThreads; ++i) {
+    const int idx = tid + kMlpThreads * i;
+    const int row = idx >> 6, c4 = idx & 63;
+    if (full || row0 + row < M)
+      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+  }
+}
+
+constexpr int kRB = kTM / 32;                    // 2 row blocks per tile
+constexpr int kCB = 8 / kMlpWaves;               // 2 column blocks per wave in a 256-wide layer
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-// NW = waves per workgroup: 4 (one per SIMD, each 128 rows x 64 cols) or 8 (two per SIMD, each
-// 128 rows x 32 cols; the second wave's MFMAs cover the first one's waits and epilogues).
-template <int NHB, bool SAVE, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_fwd_kernel(
+template <int NHB, bool SAVE>
+__global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
     const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma, float* __restrict__ acts,
     float* __restrict__ enc_out, uint32_t* __restrict__ mask) {
-  constexpr int NT = NW * 64, CPW = 8 / NW, MW = 4 * CPW * 16 / 32;
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile = blockIdx.x;
-  const int64_t row0 = tile * kTM;
-  const bool full = row0 + kTM <= M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = rgb_channels(deg);
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
-
-  posenc_tile<NT>(lds, pts, grid, row0, M, tid);
-  __syncthreads();
-  if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
-#pragma unroll
-    for (int i = 0; i < kTM * kEncPad / 4 / NT; ++i) {
-      const int idx = tid + NT * i;
-      const int row = idx >> 4, c4 = idx & 15;
-      if (row0 + row < M)
-        *reinterpret_cast<f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
-    }
-  }
-
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  f32x16 acc[4][CPW];
-  for (int l = 0; l < kDepth; ++l) {
-    zero_acc(acc);
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * CPW) * 64 + lane;
-    gemm_lds_packed<4, CPW>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
-    if (l == 5) {
-      // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
-      // columns are a second K segment; the encoding is recomputed into the consumed tile.
-      __syncthreads();
-      posenc_tile<NT>(lds, pts, grid, row0, M, tid);
-      __syncthreads();
-      gemm_lds_packed<4, CPW>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
+  const int64_t ntiles = num_tiles(M);
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kTM;
+    const bool full = row0 + kTM <= M;
+    __syncthreads();   // previous tile's head GEMM has consumed the LDS tile
+    posenc_tile(lds, pts, grid, row0, M, tid);
+    __syncthreads();
+    if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
+#pragma unroll
+      for (int i = 0; i < kTM * kEncPad / 4 / kMlpThreads; ++i) {
+        const int idx = tid + kMlpThreads * i;
+        const int row = idx >> 4, c4 = idx & 15;
+        if (full || row0 + row < M)
+          *reinterpret_cast<f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4) =
+              *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+      }
     }
-    __syncthreads();  // every wave has consumed the input tile
-    uint32_t mw[MW];
+
+    f32x16 acc[kRB][kCB];
+    for (int l = 0; l < kDepth; ++l) {
+      zero_acc(acc);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
+      gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+      if (l == 5) {
+        // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
+        // columns are a second K segment; the encoding is recomputed into the consumed tile.
+        __syncthreads();
+        posenc_tile(lds, pts, grid, row0, M, tid);
+        __syncthreads();
+        gemm_lds_packed<kRB, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
+      }
+      __syncthreads();  // every wave has consumed the input tile
+      uint32_t mw[kMaskWords];
 #pragma unroll
-    for (int w = 0; w < MW; ++w) mw[w] = 0u;
-    float* __restrict__ act_l = SAVE ? acts + (int64_t)l * M * kW + row0 * kW : nullptr;
+      for (int w = 0; w < kMaskWords; ++w) mw[w] = 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < kRB; ++r)
 #pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        const int col = (wave * CPW + c) * 32 + (lane & 31);
-        const float b = bias[l * kW + col];
+        for (int c = 0; c < kCB; ++c) {
+          const int col = (wave * kCB + c) * 32 + (lane & 31);
+          const float b = bias[l * kW + col];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = r * 32 + frag_row(reg, lane);
-          const float v = fmaxf(acc[r][c][reg] + b, 0.f);
-          lds[row * kLDA + col] = v;
-          if (SAVE) {
-            const int bit = (r * CPW + c) * 16 + reg;
-            if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
-            if (full || row0 + row < M) act_l[row * kW + col] = v;
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = r * 32 + frag_row(reg, lane);
+            const float v = fmaxf(acc[r][c][reg] + b, 0.f);
+            lds[row * kLDA + col] = v;
+            if (SAVE) {
+              const int bit = (r * kCB + c) * 16 + reg;
+              if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
+            }
+          }
+        }
+      if (SAVE) {
+        uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid) * kMaskWords;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) mp[w] = mw[w];
+      }
+      __syncthreads();
+      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid);
+    }
+
+    // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
+    // wave w owns row block w%2 and the column blocks (w/2), (w/2)+2.
+    {
+      constexpr int HMAX = (NHB + 1) / 2;
+      const int rb = wave & 1, cb0 = wave >> 1;
+      f32x16 hacc[HMAX];
+#pragma unroll
+      for (int i = 0; i < HMAX; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hacc[i][e] = 0.f;
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + lane;
+      const float* ar = arow + rb * 32 * kLDA;
+      for (int g = 0; g < 32; ++g) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ar + g * 8);
+#pragma unroll
+        for (int i = 0; i < HMAX; ++i) {
+          const int cb = cb0 + i * 2;
+          if (cb < NHB) {
+            const f32x4 b = wp[((int64_t)g * NHB + cb) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], hacc[i], 0, 0, 0);
           }
         }
       }
-    if (SAVE) {
-      uint32_t* mp = mask + ((tile * kDepth + l) * NT + tid) * MW;
-#pragma unroll
-      for (int w = 0; w < MW; ++w) mp[w] = mw[w];
-    }
-    __syncthreads();
-  }
-
-  // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
-  // wave w owns row block w%4 and the column blocks (w/4), (w/4)+NW/4, ...
-  {
-    constexpr int CSTEP = NW / 4;                       // 1 or 2
-    constexpr int HMAX = (NHB + CSTEP - 1) / CSTEP;     // column blocks per wave (upper bound)
-    const int rb = wave & 3, cb0 = wave >> 2;
-    f32x16 hacc[HMAX];
-#pragma unroll
-    for (int i = 0; i < HMAX; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) hacc[i][e] = 0.f;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + lane;
-    const float* ar = arow + rb * 32 * kLDA;
-    for (int g = 0; g < 32; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + g * 8);
+      const float* hb = bias + 8 * kW;
 #pragma unroll
       for (int i = 0; i < HMAX; ++i) {
-        const int cb = cb0 + i * CSTEP;
+        const int cb = cb0 + i * 2;
         if (cb < NHB) {
-          const f32x4 b = wp[((int64_t)g * NHB + cb) * 64];
+          const int col = cb * 32 + (lane & 31);
+          const float b = hb[col];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], hacc[i], 0, 0, 0);
-        }
-      }
-    }
-    const float* hb = bias + 8 * kW;
-#pragma unroll
-    for (int i = 0; i < HMAX; ++i) {
-      const int cb = cb0 + i * CSTEP;
-      if (cb < NHB) {
-        const int col = cb * 32 + (lane & 31);
-        const float b = hb[col];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
-          if (grow < M) {
-            const float v = hacc[i][reg] + b;
-            if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
-            else if (col == C) raw_sigma[grow] = v;
+          for (int reg = 0; reg < 16; ++reg) {
+            const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
+            if (grow < M) {
+              const float v = hacc[i][reg] + b;
+              if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
+              else if (col == C) raw_sigma[grow] = v;
+            }
           }
         }
       }
@@ -333,19 +356,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_fwd_kernel(
   }
 }
 
-int g_mlp_waves = 8;   // pxo_set_option("mlp_waves", 4|8)
-
-template <int NHB, int NW>
-static void launch_fwd_nw(const float* pk, const float* pts, const GridSpec& grid, int64_t M, int deg,
-                          float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
-                          hipStream_t s) {
-  dim3 grid_dim((unsigned)num_tiles(M)), block(NW * 64);
-  if (acts)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, NW>), grid_dim, block, 0, s, pk, pts, grid, M, deg,
-                       raw_rgb, raw_sigma, acts, enc, mask);
-  else
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, NW>), grid_dim, block, 0, s, pk, pts, grid, M, deg,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+static unsigned mlp_grid(int64_t M) {
+  const int64_t tiles = num_tiles(M), cap = 2 * (int64_t)num_cus();
+  return (unsigned)(tiles < cap ? tiles : cap);
 }
 
 template <int NHB>
@@ -353,10 +366,13 @@ static int launch_fwd_nhb(const PxoCfg* cfg, const float* pk, const float* pts, 
                           int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
                           uint32_t* mask, hipStream_t s) {
   KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
-  if (g_mlp_waves == 8)
-    launch_fwd_nw<NHB, 8>(pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma, acts, enc, mask, s);
+  dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
+  if (acts)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
+                       raw_rgb, raw_sigma, acts, enc, mask);
   else
-    launch_fwd_nw<NHB, 4>(pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma, acts, enc, mask, s);
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
+                       raw_rgb, raw_sigma, acts, enc, mask);
   return check_launch("mlp_fwd");
 }
 
@@ -392,101 +408,107 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // ------------------------------------------------------------------------------------------
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
-template <int NHB, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_bwd_data_kernel(
+template <int NHB>
+__global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg,
     float* __restrict__ dz, float* __restrict__ dbias_partial) {
-  constexpr int NT = NW * 64, CPW = 8 / NW, MW = 4 * CPW * 16 / 32;
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
   constexpr int NH = 32 * NHB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile = blockIdx.x;
-  const int64_t row0 = tile * kTM;
-  const bool full = row0 + kTM <= M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = rgb_channels(deg);
-
-  // d_raw tile -> lds[:, 0:NH] with the head's column order
-  for (int idx = tid; idx < kTM * NH; idx += NT) {
-    const int row = idx / NH, col = idx - row * NH;
-    const int64_t grow = row0 + row;
-    float v = 0.f;
-    if (grow < M) {
-      if (col < C) v = d_raw_rgb[grow * C + col];
-      else if (col == C) v = d_raw_sigma[grow];
-    }
-    lds[row * kLDA + col] = v;
-  }
-  __syncthreads();
-  if (tid < NH) {  // head bias gradient partial of this tile
-    float sum = 0.f;
-    for (int row = 0; row < kTM; ++row) sum += lds[row * kLDA + tid];
-    dbias_partial[(tile * 9 + 8) * kW + tid] = sum;
-  }
-
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  f32x16 acc[4][CPW];
-  zero_acc(acc);
-  {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * CPW) * 64 + lane;
-    gemm_lds_packed<4, CPW>(arow, wp, 4 * NHB, 8 * 64, acc);
-  }
-  for (int l = kDepth - 1; l >= 0; --l) {
-    uint32_t mw[MW];
-    const uint32_t* mp = mask + ((tile * kDepth + l) * NT + tid) * MW;
-#pragma unroll
-    for (int w = 0; w < MW; ++w) mw[w] = mp[w];
-    __syncthreads();  // previous GEMM has consumed the tile
-    float* __restrict__ dz_l = dz + (int64_t)l * M * kW + row0 * kW;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      const int col = (wave * CPW + c) * 32 + (lane & 31);
-      float colsum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = r * 32 + frag_row(reg, lane);
-          const int bit = (r * CPW + c) * 16 + reg;
-          const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
-          lds[row * kLDA + col] = v;
-          if (full || row0 + row < M) dz_l[row * kW + col] = v;
-          colsum += v;
-        }
-      colsum += __shfl_xor(colsum, 32);
-      if (lane < 32) dbias_partial[(tile * 9 + l) * kW + col] = colsum;
+  const int64_t ntiles = num_tiles(M);
+  // bias-gradient partial sums of this workgroup over all its tiles: a private [9][256] slot in
+  // global memory (L2 resident), each element read-modify-written by one fixed thread
+  float* __restrict__ my_db = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
+  for (int i = tid; i < 9 * kW; i += kMlpThreads) my_db[i] = 0.f;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kTM;
+    const bool full = row0 + kTM <= M;
+    __syncthreads();   // previous tile's stores out of LDS are done
+    // d_raw tile -> lds[:, 0:NH] with the head's column order
+    for (int idx = tid; idx < kTM * NH; idx += kMlpThreads) {
+      const int row = idx / NH, col = idx - row * NH;
+      const int64_t grow = row0 + row;
+      float v = 0.f;
+      if (grow < M) {
+        if (col < C) v = d_raw_rgb[grow * C + col];
+        else if (col == C) v = d_raw_sigma[grow];
+      }
+      lds[row * kLDA + col] = v;
     }
     __syncthreads();
-    if (l > 0) {
-      zero_acc(acc);
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * CPW) * 64 + lane;
-      gemm_lds_packed<4, CPW>(arow, wp, 32, 8 * 64, acc);
+    if (tid < NH) {  // head bias gradient
+      float sum = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < kTM; ++row) sum += lds[row * kLDA + tid];
+      my_db[8 * kW + tid] += sum;
+    }
+
+    f32x16 acc[kRB][kCB];
+    zero_acc(acc);
+    {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
+      gemm_lds_packed<kRB, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
+    }
+    for (int l = kDepth - 1; l >= 0; --l) {
+      uint32_t mw[kMaskWords];
+      const uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid) * kMaskWords;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
+      __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
+#pragma unroll
+      for (int c = 0; c < kCB; ++c) {
+        const int col = (wave * kCB + c) * 32 + (lane & 31);
+        float colsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < kRB; ++r)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = r * 32 + frag_row(reg, lane);
+            const int bit = (r * kCB + c) * 16 + reg;
+            const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
+            lds[row * kLDA + col] = v;
+            colsum += v;
+          }
+        colsum += __shfl_xor(colsum, 32);
+        if (lane < 32) my_db[l * kW + col] += colsum;
+      }
+      __syncthreads();
+      store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid);
+      if (l > 0) {
+        zero_acc(acc);
+        const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
+        gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
+      }
     }
   }
 }
 
-template <int NHB>
-static void launch_bwd_nhb(const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
-                           const uint32_t* mask, int64_t M, int deg, float* dz, float* dbias_partial,
-                           hipStream_t s) {
-  dim3 grid_dim((unsigned)num_tiles(M));
-  if (g_mlp_waves == 8)
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB, 8>), grid_dim, dim3(512), 0, s, packed_bwd, d_raw_rgb,
-                       d_raw_sigma, mask, M, deg, dz, dbias_partial);
-  else
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB, 4>), grid_dim, dim3(256), 0, s, packed_bwd, d_raw_rgb,
-                       d_raw_sigma, mask, M, deg, dz, dbias_partial);
-}
+int mlp_bwd_partials(int64_t M) { return (int)mlp_grid(M); }
 
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
                         float* dbias_partial, hipStream_t s) {
   if (M == 0) return PXO_OK;
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
+  dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
   switch (head_blocks(cfg->sh_deg)) {
-    case 1: launch_bwd_nhb<1>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
-    case 2: launch_bwd_nhb<2>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
-    default: launch_bwd_nhb<3>(packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, cfg->sh_deg, dz, dbias_partial, s); break;
+    case 1:
+      hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
+                         mask, M, cfg->sh_deg, dz, dbias_partial);
+      break;
+    case 2:
+      hipLaunchKernelGGL((mlp_bwd_data_kernel<2>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
+                         mask, M, cfg->sh_deg, dz, dbias_partial);
+      break;
+    default:
+      hipLaunchKernelGGL((mlp_bwd_data_kernel<3>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
+                         mask, M, cfg->sh_deg, dz, dbias_partial);
+      break;
   }
   return check_launch("mlp_bwd_data");
 }

@@ -31,6 +31,18 @@ int check_launch(const char* what) {
   return PXO_OK;
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    if (2 * n > kMaxMlpGrid) n = kMaxMlpGrid / 2;
+  }
+  return n;
+}
+
 int validate_cfg(const PxoCfg* cfg) {
   PXO_REQUIRE(cfg != nullptr, "cfg is NULL");
   PXO_REQUIRE(cfg->sh_deg >= 0 && cfg->sh_deg <= 4, "sh_deg %d not in [0,4] (nerf_sh/nerf/sh.py:69)", cfg->sh_deg);
@@ -415,17 +427,6 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   PXO_TRY(launch_finalize_stats(sc + 0, sc + 1, sc + 2, sc + 3, B, Nf > 0, t.n_sp, cfg->sparsity_weight, 2 * n_mlp,
                                 stats, s));
   return PXO_OK;
-}
-
-int pxo_set_option(const char* name, int value) {
-  PXO_REQUIRE(name != nullptr, "pxo_set_option: NULL name");
-  if (strcmp(name, "mlp_waves") == 0) {
-    PXO_REQUIRE(value == 4 || value == 8, "mlp_waves must be 4 or 8 (got %d)", value);
-    g_mlp_waves = value;
-    return PXO_OK;
-  }
-  set_error("pxo_set_option: unknown option %s", name);
-  return PXO_ERR_ARG;
 }
 
 int pxo_profile_enable(int on) {

@@ -14,12 +14,12 @@ constexpr int kW = PXO_NET_WIDTH;        // 256
 constexpr int kDepth = PXO_NET_DEPTH;    // 8
 constexpr int kEnc = PXO_ENC_DIM;        // 63
 constexpr int kEncPad = PXO_ENC_PAD;     // 64
-constexpr int kTM = PXO_TILE_ROWS;       // 128 rows per workgroup
+constexpr int kTM = PXO_TILE_ROWS;       // 64 rows per tile of the fused MLP kernels
 constexpr int kLDA = 260;                // LDS row stride (floats): 256 + one b128 access of pad
-constexpr int kFwdThreads = 256;         // 4 waves, each 128 rows x 64 cols
-constexpr int kFwdWaves = kFwdThreads / 64;
-constexpr int kCPW = 8 / kFwdWaves;      // 32-col blocks per wave in a 256-wide layer
-constexpr int kMaskWords = 4 * kCPW * 16 / 32;  // relu-mask words per thread per layer
+constexpr int kMlpThreads = 256;         // 4 waves, each 64 rows x 64 cols; two workgroups per CU
+constexpr int kMlpWaves = kMlpThreads / 64;
+constexpr int kMaskWords = (kTM / 32) * (8 / kMlpWaves) * 16 / 32;  // relu-mask words per thread per layer
+constexpr int kMaxMlpGrid = 1024;        // upper bound on persistent workgroups (2 per CU)
 
 // ---- derived sizes -----------------------------------------------------------------
 __host__ __device__ inline int sh_dim(int deg) { return (deg + 1) * (deg + 1); }
@@ -79,10 +79,10 @@ __host__ __device__ inline int64_t bwd_image_floats(int deg) { return bwd_layer_
 // relu-mask image written by the forward kernel: per (tile, layer, thread) kMaskWords words
 __host__ __device__ inline int64_t num_tiles(int64_t M) { return (M + kTM - 1) / kTM; }
 __host__ __device__ inline int64_t mask_words(int64_t M) {
-  return num_tiles(M) * kDepth * kFwdThreads * kMaskWords;
+  return num_tiles(M) * kDepth * kMlpThreads * kMaskWords;
 }
-// per-tile bias-gradient partials written by the backward-data kernel: [tile][9][256]
-__host__ __device__ inline int64_t dbias_floats(int64_t M) { return num_tiles(M) * 9 * kW; }
+// bias-gradient partials written by the backward-data kernel, one per persistent workgroup: [wg][9][256]
+__host__ __device__ inline int64_t dbias_floats(int64_t M) { (void)M; return (int64_t)kMaxMlpGrid * 9 * kW; }
 
 // ---- error plumbing ------------------------------------------------------------------
 void set_error(const char* fmt, ...);
@@ -97,7 +97,8 @@ int check_launch(const char* what);
   } while (0)
 
 int validate_cfg(const PxoCfg* cfg);
-extern int g_mlp_waves;   // 4 or 8 waves per workgroup in the fused MLP kernels
+int num_cus();
+int mlp_bwd_partials(int64_t M);   // number of [9][256] partials mlp_bwd_data writes for M rows
 
 // HIP-event bracket around one kernel launch (active only after pxo_profile_enable(1))
 struct KernelTimer {

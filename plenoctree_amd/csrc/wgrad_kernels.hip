@@ -155,7 +155,7 @@ __global__ void reduce_slab_kernel(const float* __restrict__ slab, int P, int ki
   dst[(int64_t)i * dst_ld + (n - col0)] = s;
 }
 
-// bias gradients: fixed-order sum of the per-tile partials written by mlp_bwd_data_kernel.
+// bias gradients: fixed-order sum of the per-workgroup partials written by mlp_bwd_data_kernel.
 // block = (layer 0..8, 32-column group); thread (tsub, c) sums tiles == tsub mod 8.
 __global__ void reduce_dbias_kernel(const float* __restrict__ partial, int64_t ntiles, int deg,
                                     float* __restrict__ grads) {
@@ -179,18 +179,6 @@ __global__ void reduce_dbias_kernel(const float* __restrict__ partial, int64_t n
       else if (col == C) grads[leaf_bias_off(8, deg)] = tot;
     }
   }
-}
-
-static int g_num_cus = 0;
-static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
-  }
-  return g_num_cus;
 }
 
 static void split_rows(int64_t M, int64_t* rows_per_wg, int* P) {
@@ -262,7 +250,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   reduce(kW, 32 * nhb, kW, 0, C, grads + leaf_kernel_off(9, deg), C);
   reduce(kW, 32 * nhb, kW, C, 1, grads + leaf_kernel_off(8, deg), 1);
   // biases
-  hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, num_tiles(M), deg, grads);
+  hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, (int64_t)mlp_bwd_partials(M), deg, grads);
   return check_launch("mlp_bwd_weights");
 }
 

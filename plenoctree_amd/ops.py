@@ -290,6 +290,3 @@ def profile_read(tag):
     check(_lib.load().pxo_profile_read(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(rows)), "pxo_profile_read")
     return n.value, ms.value, rows.value
 
-
-def set_option(name, value):
-    check(_lib.load().pxo_set_option(name.encode(), int(value)), "pxo_set_option")

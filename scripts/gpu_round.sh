@@ -10,16 +10,11 @@ if [ "${DO_TESTS:-1}" = "1" ]; then
   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
   tail -25 gpurun_out/pytest_gpu.log
-  PXO_MLP_WAVES=4 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "mlp or train or render or eval_points or grid or full_size" > gpurun_out/pytest_gpu_w4.log 2>&1
-  echo "pytest(w4) exit $?" >> gpurun_out/pytest_gpu_w4.log
-  tail -12 gpurun_out/pytest_gpu_w4.log
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
   tail -2 gpurun_out/smoke.log
 fi
 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
-PXO_MLP_WAVES=4 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/bench_w4.json 2> gpurun_out/bench_w4.err
-echo "bench(w4) exit $?"; cat gpurun_out/bench_w4.json; tail -3 gpurun_out/bench_w4.err
 if [ "${DO_PROF:-1}" = "1" ]; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"

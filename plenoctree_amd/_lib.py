@@ -95,7 +95,7 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("PXO_LIB") or LIB_PATH
     # torch must load (and initialise) its HIP runtime first: the library then binds to the same
     # libamdhip64 instance, so device pointers and streams are shared with torch.
     import torch

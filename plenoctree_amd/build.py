@@ -19,16 +19,28 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    """hipcc --offload-arch=gfx950 -> plenoctree_amd/libplenoctree_hip.so"""
+def build(force=False, verbose=True, extra_flags=(), suffix=""):
+    """hipcc --offload-arch=gfx950 -> plenoctree_amd/libplenoctree_hip<suffix>.so
+    (`suffix`/`extra_flags` build A/B variants of the kernels, selected at run time with PXO_LIB)."""
+    global LIB
+    if suffix:
+        lib_main, LIB = LIB, LIB.replace(".so", suffix + ".so")
+        try:
+            return _build(True, verbose, extra_flags, "build" + suffix)
+        finally:
+            LIB = lib_main
     if not force and not _stale():
         return LIB
+    return _build(force, verbose, extra_flags, "build")
+
+
+def _build(force, verbose, extra_flags, objdir):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -53,3 +65,5 @@ def build(force=False, verbose=True, extra_flags=()):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--variants" in sys.argv:   # previous-generation inner loops, for in-session A/B runs
+        build(suffix="_v1", extra_flags=("-DPXO_GEMM_PREFETCH1", "-DPXO_WGRAD_V1"))

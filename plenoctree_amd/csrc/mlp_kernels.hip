@@ -191,6 +191,19 @@ __device__ __forceinline__ void load_group(const float* __restrict__ arow, const
   for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + g * 8);
 }
 
+template <int RBN>
+__device__ __forceinline__ void load_a(const float* __restrict__ arow, int g, f32x4 (&a)[RBN]) {
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + g * 8);
+}
+template <int CBN>
+__device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int kg_stride, f32x4 (&b)[CBN]) {
+#pragma unroll
+  for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
+}
+
+#ifdef PXO_GEMM_PREFETCH1
+// one k-group of look-ahead for both operands (kgroups even)
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
@@ -204,6 +217,33 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
     mfma_group<RBN, CBN>(a1, b1, acc);
   }
 }
+#else
+// B (weights, L2 latency) is fetched two k-groups ahead into four rotating register sets, A (LDS)
+// one group ahead into two; kgroups must be a multiple of 4.  No register copies.
+template <int RBN, int CBN>
+__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
+  f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
+  const int last = kgroups - 1;
+  load_b<CBN>(wp, 0, kg_stride, b0);
+  load_b<CBN>(wp, 1, kg_stride, b1);
+  load_a<RBN>(arow, 0, a0);
+  for (int g = 0; g < kgroups; g += 4) {
+    load_a<RBN>(arow, g + 1, a1);
+    load_b<CBN>(wp, g + 2, kg_stride, b2);
+    mfma_group<RBN, CBN>(a0, b0, acc);
+    load_a<RBN>(arow, g + 2, a0);
+    load_b<CBN>(wp, g + 3, kg_stride, b3);
+    mfma_group<RBN, CBN>(a1, b1, acc);
+    load_a<RBN>(arow, g + 3, a1);
+    load_b<CBN>(wp, g + 4 < last ? g + 4 : last, kg_stride, b0);    // harmless re-load on the last trip
+    mfma_group<RBN, CBN>(a0, b2, acc);
+    load_a<RBN>(arow, g + 4 < last ? g + 4 : last, a0);
+    load_b<CBN>(wp, g + 5 < last ? g + 5 : last, kg_stride, b1);
+    mfma_group<RBN, CBN>(a1, b3, acc);
+  }
+}
+#endif
 
 template <int RBN, int CBN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {

@@ -11,38 +11,52 @@
 
 namespace pxo {
 
-constexpr int kKC = 32;           // rows per staged chunk
-constexpr int kWgThreads = 512;   // 8 waves
+constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
 
-template <int KIN, int NOUT, int WR, int WC, bool HEAD>
-__global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
+// Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over
+// NSPLIT workgroups (each owns NOUT/NSPLIT output columns and re-reads X; the NSPLIT partners of a
+// row range are placed 8 blocks apart = on the same XCD so the second read of X hits L2).
+template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT>
+__global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
-    int C, int64_t M, int64_t rows_per_wg, float* __restrict__ slab) {
-  static_assert(WR * WC == 8, "8 waves");
-  constexpr int RB = KIN / 32 / WR, CB = NOUT / 32 / WC;
-  constexpr int XV = kKC * KIN / 4 / kWgThreads;              // float4 per thread per X chunk
-  constexpr int ZV = HEAD ? kKC * NOUT / kWgThreads           // scalars per thread (head)
-                          : kKC * NOUT / 4 / kWgThreads;      // float4 per thread
-  static_assert(XV >= 1 && ZV >= 1, "tile too small");
-  __shared__ __attribute__((aligned(16))) float xs[2][kKC * KIN];
-  __shared__ __attribute__((aligned(16))) float zs[2][kKC * NOUT];
+    int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab) {
+  static_assert(WR * WC * 64 == NT, "wave grid");
+  constexpr int NTILE = NOUT / NSPLIT;
+  constexpr int RB = KIN / 32 / WR, CB = NTILE / 32 / WC;
+  constexpr int XV = KCH * KIN / 4 / NT;                      // float4 per thread per X chunk
+  constexpr int ZV = HEAD ? KCH * NTILE / NT                  // scalars per thread (head)
+                          : KCH * NTILE / 4 / NT;             // float4 per thread
+  static_assert(XV >= 1 && ZV >= 1 && RB >= 1 && CB >= 1, "tile too small");
+  static_assert(!HEAD || NSPLIT == 1, "head is not split");
+  __shared__ __attribute__((aligned(16))) float xs[2][KCH * KIN];
+  __shared__ __attribute__((aligned(16))) float zs[2][KCH * NTILE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
-  const int64_t r_begin = blockIdx.x * rows_per_wg;
+  int p, half;
+  if (NSPLIT == 1) { p = blockIdx.x; half = 0; }
+  else {
+    const int grp = blockIdx.x / (8 * NSPLIT), r = blockIdx.x % (8 * NSPLIT);
+    p = grp * 8 + (r & 7);
+    half = r >> 3;
+  }
+  if (p >= P) return;
+  const int ncol0 = half * NTILE;
+  const int64_t r_begin = (int64_t)p * rows_per_wg;
   int64_t r_end = r_begin + rows_per_wg;
   if (r_end > M) r_end = M;
-  const int nchunks = (int)((r_end - r_begin + kKC - 1) / kKC);
+  const int nchunks = (int)((r_end - r_begin + KCH - 1) / KCH);
 
   f32x4 xr[XV];
   f32x4 zr4[HEAD ? 1 : ZV];
   float zr1[HEAD ? ZV : 1];
 
   auto load_chunk = [&](int ch) {
-    const int64_t r0 = r_begin + (int64_t)ch * kKC;
+    const int64_t r0 = r_begin + (int64_t)ch * KCH;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int idx = tid + kWgThreads * i;
+      const int idx = tid + NT * i;
       const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
       const int64_t grow = r0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -52,8 +66,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
     if (HEAD) {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + kWgThreads * i;
-        const int row = idx / NOUT, col = idx % NOUT;
+        const int idx = tid + NT * i;
+        const int row = idx / NTILE, col = idx % NTILE;
         const int64_t grow = r0 + row;
         float v = 0.f;
         if (grow < r_end) {
@@ -65,11 +79,11 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
     } else {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + kWgThreads * i;
-        const int row = idx / (NOUT / 4), c4 = idx % (NOUT / 4);
+        const int idx = tid + NT * i;
+        const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
         const int64_t grow = r0 + row;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (grow < r_end) v = *reinterpret_cast<const f32x4*>(dZ + grow * NOUT + c4 * 4);
+        if (grow < r_end) v = *reinterpret_cast<const f32x4*>(dZ + grow * NOUT + ncol0 + c4 * 4);
         zr4[i] = v;
       }
     }
@@ -77,16 +91,16 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int idx = tid + kWgThreads * i;
+      const int idx = tid + NT * i;
       *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = xr[i];
     }
     if (HEAD) {
 #pragma unroll
-      for (int i = 0; i < ZV; ++i) zs[buf][tid + kWgThreads * i] = zr1[i];
+      for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = zr1[i];
     } else {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + kWgThreads * i;
+        const int idx = tid + NT * i;
         *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = zr4[i];
       }
     }
@@ -109,14 +123,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
     const int buf = ch & 1;
     if (ch + 1 < nchunks) load_chunk(ch + 1);
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
-    const float* zb = &zs[buf][(lane >> 5) * NOUT + (wc * CB) * 32 + (lane & 31)];
+    const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
 #pragma unroll 4
-    for (int kk = 0; kk < kKC; kk += 2) {
+    for (int kk = 0; kk < KCH; kk += 2) {
       float a[RB], b[CB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) a[r] = xa[kk * KIN + r * 32];
 #pragma unroll
-      for (int c = 0; c < CB; ++c) b[c] = zb[kk * NOUT + c * 32];
+      for (int c = 0; c < CB; ++c) b[c] = zb[kk * NTILE + c * 32];
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
@@ -127,12 +141,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
     __syncthreads();
   }
 
-  float* out = slab + (int64_t)blockIdx.x * KIN * NOUT;
+  float* out = slab + (int64_t)p * KIN * NOUT;
 #pragma unroll
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-      const int n = (wc * CB + c) * 32 + (lane & 31);
+      const int n = ncol0 + (wc * CB + c) * 32 + (lane & 31);
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int i = (wr * RB + r) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -141,18 +155,38 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(
     }
 }
 
-// dst[i*dst_ld + (n-col0)] = sum_p slab[p][i][n]   for i < rows_valid, col0 <= n < col0+ncols
-__global__ void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
-                                   int rows_valid, int col0, int ncols, float* __restrict__ dst,
-                                   int dst_ld) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows_valid * ncols) return;
-  const int i = idx / ncols, n = col0 + idx % ncols;
-  const int64_t e = (int64_t)i * nout + n;
-  const int64_t stride = (int64_t)kin * nout;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += slab[p * stride + e];
-  dst[(int64_t)i * dst_ld + (n - col0)] = s;
+// dst[i*dst_ld + (n-col0)] = sum_p slab[p][i][n]   for i < rows_valid, col0 <= n < col0+ncols.
+// Block = 64 float4 columns x 4 partial groups: thread (q, v) adds slabs p = q, q+4, ... for the
+// float4 at element 4*(64*blockIdx.x + v); the four partial sums are combined through LDS in a
+// fixed order (deterministic).  16 B loads, P/4 of them per thread.
+__global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
+                                                          int rows_valid, int col0, int ncols,
+                                                          float* __restrict__ dst, int dst_ld) {
+  __shared__ f32x4 red[4][64];
+  const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t e4 = (int64_t)blockIdx.x * 64 + v;            // float4 index inside one slab
+  const int64_t stride4 = (int64_t)kin * nout / 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e4 < stride4) {
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(slab) + e4;
+#pragma unroll 8
+    for (int p = q; p < P; p += 4) s += src[p * stride4];
+  }
+  red[q][v] = s;
+  __syncthreads();
+  if (q == 0 && e4 < stride4) {
+    f32x4 t = red[0][v];
+    t += red[1][v]; t += red[2][v]; t += red[3][v];
+    const int64_t e = e4 * 4;
+    const int i = (int)(e / nout), n0 = (int)(e % nout);
+    if (i < rows_valid) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= col0 && n < col0 + ncols) dst[(int64_t)i * dst_ld + (n - col0)] = t[j];
+      }
+    }
+  }
 }
 
 // bias gradients: fixed-order sum of the per-workgroup partials written by mlp_bwd_data_kernel.
@@ -200,8 +234,8 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
 template <int NHB>
 static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const float* d_raw_sigma, int C,
                               int64_t M, int64_t rpw, int P, float* slab, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 8, 1, true>), dim3(P), dim3(kWgThreads), 0, s, X, d_raw_rgb,
-                     d_raw_sigma, C, M, rpw, slab);
+  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 8, 1, true, 512, 32, 1>), dim3(P), dim3(512), 0, s, X, d_raw_rgb,
+                     d_raw_sigma, C, M, rpw, P, slab);
 }
 
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
@@ -220,26 +254,32 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   float* slab = reinterpret_cast<float*>(ws);
   const int64_t MW = M * kW;
   auto reduce = [&](int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld) {
-    const int n = rows_valid * ncols;
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slab, P, kin, nout,
+    const int n4 = kin * nout / 4;
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((n4 + 63) / 64), dim3(256), 0, s, slab, P, kin, nout,
                        rows_valid, col0, ncols, dst, dst_ld);
   };
   // Dense_0: enc^T dz_0  (63 valid input rows)
-  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false>), dim3(P), dim3(kWgThreads), 0, s, enc, dz,
-                     nullptr, 0, M, rpw, slab);
+  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc, dz,
+                     nullptr, 0, M, rpw, P, slab);
   reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW);
   // Dense_1..7: h_{l-1}^T dz_l  (for l = 5 these are the first 256 input rows)
   for (int l = 1; l < kDepth; ++l) {
     {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 2, false>), dim3(P), dim3(kWgThreads), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, slab);
+#ifdef PXO_WGRAD_V1
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 2, false, 512, 32, 1>), dim3(P), dim3(512), 0, s,
+                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
+#else
+    // 256x256 product as two independent 4-wave workgroups per CU (256 x 128 each, 16-row chunks)
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
+                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
+#endif
     }
     reduce(kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW);
   }
   // Dense_5 skip rows 256..318: enc^T dz_5
-  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false>), dim3(P), dim3(kWgThreads), 0, s, enc,
-                     dz + (int64_t)5 * MW, nullptr, 0, M, rpw, slab);
+  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc,
+                     dz + (int64_t)5 * MW, nullptr, 0, M, rpw, P, slab);
   reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
   // heads: h7^T [d_raw_rgb | d_raw_sigma]
   const float* h7 = acts + (int64_t)7 * MW;

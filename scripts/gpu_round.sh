@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$PWD
 nproc > gpurun_out/device.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/device.txt
 if [ "${DO_TESTS:-1}" = "1" ]; then
-  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
   tail -25 gpurun_out/pytest_gpu.log
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log

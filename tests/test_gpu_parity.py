@@ -580,12 +580,18 @@ def test_cli_train_eval_extraction(tmp_path):
     _gpu()
     from plenoctree_amd.nerf_sh import train, eval as eval_mod
     from plenoctree_amd.octree import extraction
-    common = ["--train_dir", str(tmp_path), "--config", "synthetic"]
-    trace = train.main(common + ["--batch_size", "2048", "--max_steps", "60", "--print_every", "20", "--save_every", "60",
-                                 "--render_every", "0", "--lr_init", "5e-4"])
+    # NB: like the reference (nerf_sh/nerf/utils.py:233-244) the YAML preset overrides command-line
+    # flags for the keys it contains, so the short schedule has to live in the YAML itself.
+    cfg_path = os.path.join(str(tmp_path), "short.yaml")
+    with open(cfg_path, "w") as f:
+        f.write("dataset: synthetic\nfactor: 4\nnum_coarse_samples: 64\nnum_fine_samples: 128\nuse_viewdirs: false\n"
+                "white_bkgd: true\nbatch_size: 2048\nsh_deg: 3\nrandomized: true\nmax_steps: 60\nprint_every: 20\n"
+                "save_every: 60\nrender_every: 0\n")
+    common = ["--train_dir", str(tmp_path), "--config", cfg_path]
+    trace = train.main(common)
     assert len(trace) == 3 and trace[-1][1] < trace[0][1], trace          # (step, loss, psnr, rays/s)
     assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_60"))
-    psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])
+    psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0
     sig = extraction.main(common + ["--init_grid_depth", "4"])             # 32^3 grid
     assert sig.shape == (32 ** 3,) and bool(torch.isfinite(sig).all())

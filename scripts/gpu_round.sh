@@ -15,6 +15,10 @@ if [ "${DO_TESTS:-1}" = "1" ]; then
 fi
 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+if [ -f plenoctree_amd/libplenoctree_hip_v1.so ]; then
+  PXO_LIB=$R/plenoctree_amd/libplenoctree_hip_v1.so timeout 300 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/bench_v1.json 2> gpurun_out/bench_v1.err
+  echo "bench(v1 variant) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_v1.json'));print(d['value'],[(k['kernel'],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"
+fi
 if [ "${DO_PROF:-1}" = "1" ]; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"

@@ -219,7 +219,10 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
 }
 #else
 // B (weights, L2 latency) is fetched two k-groups ahead into four rotating register sets, A (LDS)
-// one group ahead into two; kgroups must be a multiple of 4.  No register copies.
+// one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
+// sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
+// each load to just before its use and exposes the LDS/L2 latency on every k-group.
+#define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
@@ -231,16 +234,24 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
   for (int g = 0; g < kgroups; g += 4) {
     load_a<RBN>(arow, g + 1, a1);
     load_b<CBN>(wp, g + 2, kg_stride, b2);
+    PXO_PIN();
     mfma_group<RBN, CBN>(a0, b0, acc);
+    PXO_PIN();
     load_a<RBN>(arow, g + 2, a0);
     load_b<CBN>(wp, g + 3, kg_stride, b3);
+    PXO_PIN();
     mfma_group<RBN, CBN>(a1, b1, acc);
+    PXO_PIN();
     load_a<RBN>(arow, g + 3, a1);
     load_b<CBN>(wp, g + 4 < last ? g + 4 : last, kg_stride, b0);    // harmless re-load on the last trip
+    PXO_PIN();
     mfma_group<RBN, CBN>(a0, b2, acc);
+    PXO_PIN();
     load_a<RBN>(arow, g + 4 < last ? g + 4 : last, a0);
     load_b<CBN>(wp, g + 5 < last ? g + 5 : last, kg_stride, b1);
+    PXO_PIN();
     mfma_group<RBN, CBN>(a1, b3, acc);
+    PXO_PIN();
   }
 }
 #endif
@@ -316,11 +327,25 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
         // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
         // columns are a second K segment; the encoding is recomputed into the consumed tile.
         __syncthreads();
+#if !defined(PXO_ABLATE) || PXO_ABLATE < 2
         posenc_tile(lds, pts, grid, row0, M, tid);
+#endif
         __syncthreads();
         gemm_lds_packed<kRB, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
       }
+#if defined(PXO_ABLATE) && PXO_ABLATE >= 3
+#pragma unroll
+      for (int r = 0; r < kRB; ++r)
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) asm volatile("" ::"v"(acc[r][c]));
+      continue;
+#endif
       __syncthreads();  // every wave has consumed the input tile
+      // re-derive the lane ids from an opaque copy so that the epilogue / store addresses are
+      // computed here instead of being hoisted out of the loops into (scarce) registers
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));
+      const int lane_e = tid_e & 63;
       uint32_t mw[kMaskWords];
 #pragma unroll
       for (int w = 0; w < kMaskWords; ++w) mw[w] = 0u;
@@ -328,11 +353,11 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
       for (int r = 0; r < kRB; ++r)
 #pragma unroll
         for (int c = 0; c < kCB; ++c) {
-          const int col = (wave * kCB + c) * 32 + (lane & 31);
+          const int col = (wave * kCB + c) * 32 + (lane_e & 31);
           const float b = bias[l * kW + col];
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) {
-            const int row = r * 32 + frag_row(reg, lane);
+            const int row = r * 32 + frag_row(reg, lane_e);
             const float v = fmaxf(acc[r][c][reg] + b, 0.f);
             lds[row * kLDA + col] = v;
             if (SAVE) {
@@ -341,13 +366,19 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
             }
           }
         }
+#if !defined(PXO_ABLATE)
       if (SAVE) {
-        uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid) * kMaskWords;
+        uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) mp[w] = mw[w];
       }
+#else
+      asm volatile("" ::"v"(mw[0]), "v"(mw[kMaskWords - 1]));
+#endif
       __syncthreads();
-      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid);
+#if !defined(PXO_ABLATE)
+      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
+#endif
     }
 
     // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
@@ -500,25 +531,28 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
 #pragma unroll
       for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
       __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));   // see mlp_fwd_kernel: keeps the epilogue addresses out of the loops' live set
+      const int lane_e = tid_e & 63;
 #pragma unroll
       for (int c = 0; c < kCB; ++c) {
-        const int col = (wave * kCB + c) * 32 + (lane & 31);
+        const int col = (wave * kCB + c) * 32 + (lane_e & 31);
         float colsum = 0.f;
 #pragma unroll
         for (int r = 0; r < kRB; ++r)
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) {
-            const int row = r * 32 + frag_row(reg, lane);
+            const int row = r * 32 + frag_row(reg, lane_e);
             const int bit = (r * kCB + c) * 16 + reg;
             const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
             lds[row * kLDA + col] = v;
             colsum += v;
           }
         colsum += __shfl_xor(colsum, 32);
-        if (lane < 32) my_db[l * kW + col] += colsum;
+        if (lane_e < 32) my_db[l * kW + col] += colsum;
       }
       __syncthreads();
-      store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid);
+      store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
       if (l > 0) {
         zero_acc(acc);
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;

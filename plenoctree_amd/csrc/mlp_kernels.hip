@@ -321,6 +321,9 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
     f32x16 acc[kRB][kCB];
     for (int l = 0; l < kDepth; ++l) {
       zero_acc(acc);
+      float bl[kCB];                       // this layer's biases, fetched under the GEMM
+#pragma unroll
+      for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
       gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
       if (l == 5) {
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
 #pragma unroll
         for (int c = 0; c < kCB; ++c) {
           const int col = (wave * kCB + c) * 32 + (lane_e & 31);
-          const float b = bias[l * kW + col];
+          const float b = bl[c];
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) {
             const int row = r * 32 + frag_row(reg, lane_e);
@@ -484,16 +487,16 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg,
     float* __restrict__ dz, float* __restrict__ dbias_partial) {
-  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
+  // activation-gradient tile + this workgroup's bias-gradient accumulators [9][256] (each element is
+  // read-modify-written by one fixed thread; kept in LDS so the epilogue never waits on memory)
+  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + 9 * kW];
+  float* __restrict__ my_db = lds + kTM * kLDA;
   constexpr int NH = 32 * NHB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = rgb_channels(deg);
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
   const int64_t ntiles = num_tiles(M);
-  // bias-gradient partial sums of this workgroup over all its tiles: a private [9][256] slot in
-  // global memory (L2 resident), each element read-modify-written by one fixed thread
-  float* __restrict__ my_db = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
   for (int i = tid; i < 9 * kW; i += kMlpThreads) my_db[i] = 0.f;
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -521,15 +524,15 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
 
     f32x16 acc[kRB][kCB];
     zero_acc(acc);
+    uint32_t mw[kMaskWords];   // relu-mask words of the layer whose gradient the running GEMM produces
     {
+      const uint32_t* mp = mask + ((tile * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
       gemm_lds_packed<kRB, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
     }
     for (int l = kDepth - 1; l >= 0; --l) {
-      uint32_t mw[kMaskWords];
-      const uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid) * kMaskWords;
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
       __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
       int tid_e = tid;
       asm volatile("" : "+v"(tid_e));   // see mlp_fwd_kernel: keeps the epilogue addresses out of the loops' live set
@@ -555,11 +558,18 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
       store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
       if (l > 0) {
         zero_acc(acc);
+        const uint32_t* mp = mask + ((tile * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
         gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
       }
     }
   }
+  __syncthreads();
+  // one partial per workgroup: [wg][9][256]
+  float* out = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
+  for (int i = tid; i < 9 * kW; i += kMlpThreads) out[i] = my_db[i];
 }
 
 int mlp_bwd_partials(int64_t M) { return (int)mlp_grid(M); }

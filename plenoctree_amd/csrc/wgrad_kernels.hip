@@ -59,9 +59,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       const int idx = tid + NT * i;
       const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
       const int64_t grow = r0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (grow < r_end) v = *reinterpret_cast<const f32x4*>(X + grow * KIN + c4 * 4);
-      xr[i] = v;
+      const bool ok = grow < r_end;                      // rows past the range contribute zeros
+      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);
+      xr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (HEAD) {
 #pragma unroll
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
         const int idx = tid + NT * i;
         const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
         const int64_t grow = r0 + row;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (grow < r_end) v = *reinterpret_cast<const f32x4*>(dZ + grow * NOUT + ncol0 + c4 * 4);
-        zr4[i] = v;
+        const bool ok = grow < r_end;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
+        zr4[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -124,18 +124,33 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     if (ch + 1 < nchunks) load_chunk(ch + 1);
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
-#pragma unroll 4
-    for (int kk = 0; kk < KCH; kk += 2) {
-      float a[RB], b[CB];
+    // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
+    // otherwise sinks every ds_read to just before its use and waits lgkmcnt(0) every 4 MFMAs)
+    float a0[RB], b0[CB], a1[RB], b1[CB];
+    auto read_step = [&](int kk, float (&a)[RB], float (&b)[CB]) {
 #pragma unroll
       for (int r = 0; r < RB; ++r) a[r] = xa[kk * KIN + r * 32];
 #pragma unroll
       for (int c = 0; c < CB; ++c) b[c] = zb[kk * NTILE + c * 32];
+    };
+    auto mfma_step = [&](const float (&a)[RB], const float (&b)[CB]) {
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < CB; ++c)
           acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[c], acc[r][c], 0, 0, 0);
+    };
+    read_step(0, a0, b0);
+#pragma unroll
+    for (int kk = 0; kk < KCH; kk += 4) {
+      read_step(kk + 2, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_step(kk + 4 < KCH ? kk + 4 : kk + 2, a0, b0);   // harmless re-read on the last trip
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();

@@ -52,16 +52,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   f32x4 zr4[HEAD ? 1 : ZV];
   float zr1[HEAD ? ZV : 1];
 
+  uint32_t okx = 0u, okz = 0u;   // per-thread validity bits of the rows held in xr / zr4
   auto load_chunk = [&](int ch) {
     const int64_t r0 = r_begin + (int64_t)ch * KCH;
+    okx = 0u; okz = 0u;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
       const int64_t grow = r0 + row;
-      const bool ok = grow < r_end;                      // rows past the range contribute zeros
-      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);
-      xr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = grow < r_end;                      // rows past the range contribute zeros:
+      okx |= (ok ? 1u : 0u) << i;                        // selected at store time, so that nothing
+      xr[i] = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);  // waits here
     }
     if (HEAD) {
 #pragma unroll
@@ -83,8 +85,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
         const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
         const int64_t grow = r0 + row;
         const bool ok = grow < r_end;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
-        zr4[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        okz |= (ok ? 1u : 0u) << i;
+        zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
       }
     }
   };
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + NT * i;
-      *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = xr[i];
+      *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((okx >> i) & 1u) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (HEAD) {
 #pragma unroll
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
         const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = zr4[i];
+        *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((okz >> i) & 1u) ? zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };

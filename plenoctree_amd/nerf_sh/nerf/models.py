@@ -45,14 +45,6 @@ class TrainState:
             self._ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.params.device)
         return self._ws
 
-    def state_dict(self):
-        return {"params": self.params.cpu(), "m": self.m.cpu(), "v": self.v.cpu(), "step": self.step}
-
-    def load_state_dict(self, sd):
-        self.params.copy_(sd["params"]); self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
-        self.step = int(sd["step"])
-        self.repack()
-
 
 def glorot_uniform_(w, fan_in, fan_out, gen):
     lim = math.sqrt(6.0 / (fan_in + fan_out))

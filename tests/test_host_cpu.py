@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import nerf_oracle as O
-from plenoctree_amd.nerf_sh.nerf import checkpoints, datasets, utils
+from plenoctree_amd.nerf_sh.nerf import datasets, utils
 
 
 def _args(argv=()):
@@ -98,26 +98,3 @@ def test_blender_loader(tmp_path):
     np.testing.assert_allclose(ds.images[1].numpy().reshape(8, 8, 3), want, rtol=1e-6)
     b = next(ds)
     assert b["pixels"].shape == (16, 3)
-
-
-class _FakeState:
-    def __init__(self):
-        self.params = torch.arange(5.0); self.m = torch.zeros(5); self.v = torch.ones(5); self.step = 7
-
-    def state_dict(self):
-        return {"params": self.params, "m": self.m, "v": self.v, "step": self.step}
-
-    def load_state_dict(self, sd):
-        self.params, self.m, self.v, self.step = sd["params"], sd["m"], sd["v"], int(sd["step"])
-
-
-def test_checkpoint_roundtrip_and_keep(tmp_path):
-    st = _FakeState()
-    assert checkpoints.restore_checkpoint(str(tmp_path), st) is None
-    for step in (10, 20, 30):
-        st.step = step; st.params = st.params + 1
-        checkpoints.save_checkpoint(str(tmp_path), st, step, keep=2)
-    assert sorted(os.listdir(tmp_path)) == ["checkpoint_20", "checkpoint_30"]
-    fresh = _FakeState()
-    assert checkpoints.restore_checkpoint(str(tmp_path), fresh).endswith("checkpoint_30")
-    assert fresh.step == 30 and torch.equal(fresh.params, st.params)

@@ -150,6 +150,21 @@ int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* or
 int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out,
                 void* stream);
 
+/* Uniform integers in [0, n) from the same counter-based generator (np.random.randint in
+ * Dataset._next_train, nerf_sh/nerf/datasets.py:159-166). */
+int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, void* stream);
+
+/* generate_rays (nerf_sh/nerf/utils.py:545-589, pinhole branch) for B pixels of one camera:
+ * c2w = first 3 rows of the 4x4 camera-to-world matrix (12 floats, row-major, device), pixel id
+ * p -> (x = p % W, y = p / W); pixel_ids may be NULL (ids 0..B-1 = a whole image). */
+int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pixel_ids, int64_t B,
+                      float* origins, float* directions, float* viewdirs, void* stream);
+
+/* Step 2 of the extraction (octree/extraction.py:391-393, SH/SG formats): mean over the S samples
+ * of each leaf of cat([raw_rgb, raw_sigma]); out [n_cells, 3K+1]. */
+int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, int64_t n_cells,
+                          int S, float* out, void* stream);
+
 /* flax.optim.Adam.apply_gradient (call site nerf_sh/train.py:119; beta1 .9, beta2 .999,
  * eps 1e-8), with g = grads*grad_scale (grad_scale = 1/world_size after an RCCL sum).
  * `step` = number of updates already applied. */

@@ -328,6 +328,25 @@ int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi
   return launch_uniform(seed, stream_id, n, lo, hi, out, (hipStream_t)stream);
 }
 
+int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, void* stream) {
+  PXO_REQUIRE(count >= 0 && n >= 1 && out, "pxo_randint: bad arguments");
+  return launch_randint(seed, stream_id, count, n, out, (hipStream_t)stream);
+}
+
+int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pixel_ids, int64_t B,
+                      float* origins, float* directions, float* viewdirs, void* stream) {
+  PXO_REQUIRE(B >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && origins && directions && viewdirs,
+              "pxo_generate_rays: bad arguments");
+  return launch_generate_rays(c2w, W, H, focal, pixel_ids, B, origins, directions, viewdirs, (hipStream_t)stream);
+}
+
+int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S,
+                          float* out, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(n_cells >= 0 && S >= 1 && raw_rgb && raw_sigma && out, "pxo_mean_over_samples: bad arguments");
+  return launch_mean_samples(raw_rgb, raw_sigma, n_cells, S, rgb_channels(cfg->sh_deg), out, (hipStream_t)stream);
+}
+
 int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t n, float lr, int64_t step,
                   float grad_scale, void* stream) {
   PXO_REQUIRE(n >= 0 && params && m && v && grads && step >= 0, "pxo_adam_step: bad arguments");

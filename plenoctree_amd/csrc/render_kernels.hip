@@ -415,6 +415,69 @@ int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// generate_rays for a batch of pixels of one camera (nerf_sh/nerf/utils.py:545-589, pinhole):
+// pixel id p -> x = p % W, y = p / W (integer pixel centres), dir_cam = [(x-W/2)/f, -(y-H/2)/f, -1],
+// direction = R dir_cam (not normalised), origin = c2w[:3,3], viewdir = direction / |direction|
+// ------------------------------------------------------------------------------------------
+__global__ void generate_rays_kernel(const float* __restrict__ c2w, int W, int H, float focal,
+                                     const int64_t* __restrict__ pix, int64_t B, float* __restrict__ o,
+                                     float* __restrict__ d, float* __restrict__ v) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int64_t p = pix ? pix[i] : i;
+  const float x = (float)(p % W), y = (float)(p / W);
+  const float cx = (x - (float)W * 0.5f) / focal, cy = -(y - (float)H * 0.5f) / focal, cz = -1.f;
+  float dir[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // numpy matmul accumulates the 3 products in order
+    dir[a] = c2w[a * 4 + 0] * cx + c2w[a * 4 + 1] * cy + c2w[a * 4 + 2] * cz;
+    o[i * 3 + a] = c2w[a * 4 + 3];
+    d[i * 3 + a] = dir[a];
+  }
+  const float n = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[i * 3 + a] = dir[a] / n;
+}
+
+int launch_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pix, int64_t B, float* o,
+                         float* d, float* v, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c2w, W, H, focal, pix,
+                     B, o, d, v);
+  return check_launch("generate_rays");
+}
+
+// uniform integers in [0, n) from the Philox stream (the role of np.random.randint in
+// Dataset._next_train, nerf_sh/nerf/datasets.py:159-166)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1);
+__global__ void randint_kernel(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* __restrict__ out);
+
+// mean over the S samples of a leaf of cat([raw_rgb, raw_sigma]) (octree/extraction.py:391-393)
+__global__ void mean_samples_kernel(const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma,
+                                    int64_t n_cells, int S, int C, float* __restrict__ out) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= n_cells * (C + 1)) return;
+  const int64_t cell = idx / (C + 1);
+  const int j = (int)(idx - cell * (C + 1));
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const int64_t row = cell * S + s;
+    sum += j < C ? raw_rgb[row * C + j] : raw_sigma[row];
+  }
+  out[idx] = sum / (float)S;
+}
+
+int launch_mean_samples(const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S, int C, float* out,
+                        hipStream_t s) {
+  if (n_cells == 0) return PXO_OK;
+  const int64_t n = n_cells * (C + 1);
+  hipLaunchKernelGGL(mean_samples_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw_rgb, raw_sigma,
+                     n_cells, S, C, out);
+  return check_launch("mean_samples");
+}
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 uniform generator
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -444,6 +507,33 @@ __global__ void uniform_kernel(uint64_t seed, uint64_t stream_id, int64_t n, flo
       out[idx] = lo + (hi - lo) * r01;
     }
   }
+}
+
+__global__ void randint_kernel(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* __restrict__ out) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q * 2 >= count) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t idx = q * 2 + i;
+    if (idx < count) {
+      const uint64_t r64 = ((uint64_t)c[2 * i] << 32) | c[2 * i + 1];
+      out[idx] = (int64_t)(r64 % (uint64_t)n);       // bias < n/2^64, negligible
+    }
+  }
+}
+
+int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, hipStream_t s) {
+  if (count == 0) return PXO_OK;
+  const int64_t q = (count + 1) / 2;
+  hipLaunchKernelGGL(randint_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, seed, stream_id, count, n, out);
+  return check_launch("randint");
 }
 
 int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, hipStream_t s) {

@@ -78,6 +78,11 @@ class Dataset:
 
     def _rays_for(self, image_index, ray_indices):
         """Rays of the chosen pixels of one image (generate_rays, utils.py:545-589), on device."""
+        if self.device.type == "cuda":      # HIP kernel; the torch expression below is the CPU-test path
+            from ... import ops
+            if not hasattr(self, "_c2w_dev"):
+                self._c2w_dev = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[:, :3, :4])).to(self.device)
+            return utils.Rays(*ops.generate_rays(self._c2w_dev[image_index], self.w, self.h, self.focal, ray_indices))
         c2w = torch.from_numpy(self.camtoworlds[image_index]).to(self.device)
         idx = ray_indices
         x = (idx % self.w).float()

@@ -73,8 +73,7 @@ def eval_leaf_samples(model, state, points, samples_per_cell):
     """Step 2 (extraction.py:367-393, SH/SG formats): [n_cells*S, 3] points -> mean over the S
     samples of cat([raw_rgb, raw_sigma]) -> [n_cells, 3K+1]."""
     rgb, sigma = model.eval_points_raw(state, points)
-    rgba = torch.cat([rgb, sigma], dim=-1)
-    return rgba.reshape(-1, samples_per_cell, rgba.shape[-1]).mean(dim=1)
+    return ops.mean_over_samples(model.cfg, rgb, sigma, samples_per_cell)
 
 
 def main(argv=None):

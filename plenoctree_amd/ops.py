@@ -290,3 +290,34 @@ def profile_read(tag):
     check(_lib.load().pxo_profile_read(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(rows)), "pxo_profile_read")
     return n.value, ms.value, rows.value
 
+
+
+def randint(seed, stream_id, count, n, device=None):
+    """count uniform integers in [0, n) (int64) from the Philox stream."""
+    _require_gpu()
+    out = _new(count, device=device, dtype=torch.int64)
+    check(_lib.load().pxo_randint(seed, stream_id, count, n, _p(out), _stream()), "pxo_randint")
+    return out
+
+
+def generate_rays(c2w, W, H, focal, pixel_ids=None, count=None):
+    """Rays of the given pixels (or of pixels 0..count-1) of one camera: (origins, directions, viewdirs)."""
+    _require_gpu()
+    c2w = c2w[:3, :4].contiguous()
+    B = pixel_ids.shape[0] if pixel_ids is not None else (count if count is not None else W * H)
+    dev = c2w.device
+    o, d, v = _new(B, 3, device=dev), _new(B, 3, device=dev), _new(B, 3, device=dev)
+    if pixel_ids is not None and pixel_ids.dtype != torch.int64:
+        raise PxoError("pixel_ids must be int64")
+    check(_lib.load().pxo_generate_rays(_f(c2w), W, H, float(focal), _p(pixel_ids), B, _f(o), _f(d), _f(v), _stream()),
+          "pxo_generate_rays")
+    return o, d, v
+
+
+def mean_over_samples(cfg, raw_rgb, raw_sigma, samples_per_cell):
+    _require_gpu()
+    n = raw_sigma.numel() // samples_per_cell
+    out = _new(n, rgb_channels(cfg) + 1, device=raw_sigma.device)
+    check(_lib.load().pxo_mean_over_samples(ctypes.byref(cfg), _f(raw_rgb), _f(raw_sigma.reshape(-1)), n,
+                                            samples_per_cell, _f(out), _stream()), "pxo_mean_over_samples")
+    return out

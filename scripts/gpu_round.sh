@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$PWD
 nproc > gpurun_out/device.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/device.txt
 if [ "${DO_TESTS:-1}" = "1" ]; then
-  timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  timeout 420 python -m pytest tests -m gpu --durations=5 -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
   tail -25 gpurun_out/pytest_gpu.log
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
@@ -15,6 +15,8 @@ if [ "${DO_TESTS:-1}" = "1" ]; then
 fi
 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+timeout 200 python bench.py --preset tt --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_tt.json 2> gpurun_out/bench_tt.err
+echo "bench(tt SH25) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_tt.json'));print(round(d['value']),d['ms_per_step'],[(k['kernel'][:14],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"
 if [ -f plenoctree_amd/libplenoctree_hip_v1.so ]; then
   PXO_LIB=$R/plenoctree_amd/libplenoctree_hip_v1.so timeout 300 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/bench_v1.json 2> gpurun_out/bench_v1.err
   echo "bench(v1 variant) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_v1.json'));print(d['value'],[(k['kernel'],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"

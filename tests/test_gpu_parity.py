@@ -663,6 +663,13 @@ def test_trained_psnr_matches_oracle_training():
     with torch.no_grad():
         ref = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
     out = model.apply(state, utils.Rays(*[r.to(dev) for r in rays]), False)[1][0].cpu()
-    psnr_ref, psnr_hip = _psnr(ref, px), _psnr(out, px)
+    with torch.no_grad():
+        init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]
+    psnr_ref, psnr_hip, psnr_init = _psnr(ref, px), _psnr(out, px), _psnr(init, px)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "trained_psnr.json"), "w") as f:
+            f.write('{"steps": %d, "rays_per_step": %d, "psnr_init": %.4f, "psnr_oracle_trained": %.4f, '
+                    '"psnr_hip_trained": %.4f}\n' % (steps, B, psnr_init, psnr_ref, psnr_hip))
     assert abs(psnr_hip - psnr_ref) <= 0.1, (psnr_hip, psnr_ref)
-    assert psnr_hip > 11.0          # training made progress from the ~8 dB initial state
+    assert psnr_hip > psnr_init + 0.3, (psnr_hip, psnr_init)     # and training made progress

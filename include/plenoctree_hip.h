@@ -39,7 +39,6 @@ extern "C" {
 #define PXO_SKIP_LAYER 4
 #define PXO_ENC_DIM 63      /* 3*(1+2*10), nerf_sh/nerf/model_utils.py:145-173 */
 #define PXO_ENC_PAD 64
-#define PXO_TILE_ROWS 64    /* rows (samples) per tile in the fused MLP kernels */
 #define PXO_NUM_LEAVES 20   /* per MLP: 10 x (kernel, bias) */
 
 /* Hyper-parameters of the path: the flags of nerf_sh/nerf/utils.py:61-230 that reach the
@@ -72,6 +71,8 @@ typedef struct PxoLeaf {
 
 const char* pxo_last_error(void);
 int pxo_version(void);
+/* Rows (samples) per tile of the fused MLP kernels in this build (64 or 128); informational. */
+int pxo_tile_rows(void);
 
 /* Parameter arena description (flax pytree flattened; replaces the pytree walk of
  * octree/nerf/models.py:75-102).  leaves must hold PXO_NUM_LEAVES entries. */

@@ -15,7 +15,6 @@ NET_DEPTH = 8
 NET_WIDTH = 256
 ENC_DIM = 63
 ENC_PAD = 64
-TILE_ROWS = 64
 NUM_LEAVES = 20
 
 
@@ -59,6 +58,7 @@ CFG = POINTER(PxoCfg)
 SIGNATURES = {
     "pxo_last_error": (c_char_p, []),
     "pxo_version": (c_int, []),
+    "pxo_tile_rows": (c_int, []),
     "pxo_param_layout": (c_int, [CFG, POINTER(PxoLeaf), POINTER(c_int64)]),
     "pxo_packed_sizes": (c_int, [CFG, POINTER(c_int64), POINTER(c_int64)]),
     "pxo_pack_weights": (c_int, [CFG, P, P, P, P]),

@@ -66,7 +66,7 @@ def _build(force, verbose, extra_flags, objdir):
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--variants" in sys.argv:   # previous-generation inner loops, for in-session A/B runs
-        build(suffix="_v1", extra_flags=("-DPXO_GEMM_PREFETCH1", "-DPXO_WGRAD_V1"))
+        build(suffix="_g0", extra_flags=("-DPXO_GEOM=0",))      # 64-row tiles, two workgroups per CU
     if "--ablations" in sys.argv:  # timing-only experiments on the forward kernel (results are wrong)
         for lvl in (1, 2, 3):
             build(suffix=f"_abl{lvl}", extra_flags=(f"-DPXO_ABLATE={lvl}",))

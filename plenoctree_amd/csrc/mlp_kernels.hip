@@ -282,14 +282,14 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
   }
 }
 
-constexpr int kRB = kTM / 32;                    // 2 row blocks per tile
-constexpr int kCB = 8 / kMlpWaves;               // 2 column blocks per wave in a 256-wide layer
+constexpr int kRB = kTM / 32;                    // row blocks per tile (all owned by every wave)
+constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 256-wide layer
 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <int NHB, bool SAVE>
-__global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
+__global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_fwd_kernel(
     const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma, float* __restrict__ acts,
     float* __restrict__ enc_out, uint32_t* __restrict__ mask) {
@@ -385,10 +385,11 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
     }
 
     // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
-    // wave w owns row block w%2 and the column blocks (w/2), (w/2)+2.
+    // wave w owns row block w % kRB and the column blocks w / kRB, w / kRB + CSTEP, ...
     {
-      constexpr int HMAX = (NHB + 1) / 2;
-      const int rb = wave & 1, cb0 = wave >> 1;
+      constexpr int CSTEP = kMlpWaves / kRB;               // waves sharing a row block
+      constexpr int HMAX = (NHB + CSTEP - 1) / CSTEP;
+      const int rb = wave % kRB, cb0 = wave / kRB;
       f32x16 hacc[HMAX];
 #pragma unroll
       for (int i = 0; i < HMAX; ++i)
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
         const f32x4 a = *reinterpret_cast<const f32x4*>(ar + g * 8);
 #pragma unroll
         for (int i = 0; i < HMAX; ++i) {
-          const int cb = cb0 + i * 2;
+          const int cb = cb0 + i * CSTEP;
           if (cb < NHB) {
             const f32x4 b = wp[((int64_t)g * NHB + cb) * 64];
 #pragma unroll
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
       const float* hb = bias + 8 * kW;
 #pragma unroll
       for (int i = 0; i < HMAX; ++i) {
-        const int cb = cb0 + i * 2;
+        const int cb = cb0 + i * CSTEP;
         if (cb < NHB) {
           const int col = cb * 32 + (lane & 31);
           const float b = hb[col];
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_kernel(
 }
 
 static unsigned mlp_grid(int64_t M) {
-  const int64_t tiles = num_tiles(M), cap = 2 * (int64_t)num_cus();
+  const int64_t tiles = num_tiles(M), cap = kMlpWgPerCu * (int64_t)num_cus();
   return (unsigned)(tiles < cap ? tiles : cap);
 }
 
@@ -483,7 +484,7 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
 template <int NHB>
-__global__ __launch_bounds__(kMlpThreads, 2) void mlp_bwd_data_kernel(
+__global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg,
     float* __restrict__ dz, float* __restrict__ dbias_partial) {

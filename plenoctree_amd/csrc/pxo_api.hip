@@ -215,6 +215,7 @@ extern "C" {
 
 const char* pxo_last_error(void) { return g_last_error.c_str(); }
 int pxo_version(void) { return 1; }
+int pxo_tile_rows(void) { return kTM; }
 
 int pxo_param_layout(const PxoCfg* cfg, PxoLeaf* leaves, int64_t* floats_per_mlp) {
   PXO_TRY(validate_cfg(cfg));

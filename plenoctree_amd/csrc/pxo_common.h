@@ -14,12 +14,27 @@ constexpr int kW = PXO_NET_WIDTH;        // 256
 constexpr int kDepth = PXO_NET_DEPTH;    // 8
 constexpr int kEnc = PXO_ENC_DIM;        // 63
 constexpr int kEncPad = PXO_ENC_PAD;     // 64
-constexpr int kTM = PXO_TILE_ROWS;       // 64 rows per tile of the fused MLP kernels
+// Geometry of the fused MLP kernels (build-time):
+//   PXO_GEOM 0: 64-row tiles, 4 waves (64 rows x 64 cols each), two independent workgroups per CU
+//   PXO_GEOM 1: 128-row tiles, 8 waves (128 rows x 32 cols each), one workgroup per CU -- half the
+//               weight-fragment loads per MFMA (scripts/ubench/gemm_geom.hip: 149.7 vs 138.3 TFLOP/s
+//               for the bare GEMM loop)
+#ifndef PXO_GEOM
+#define PXO_GEOM 1
+#endif
+#if PXO_GEOM == 0
+constexpr int kTM = 64;
+constexpr int kMlpThreads = 256;
+constexpr int kMlpWgPerCu = 2;
+#else
+constexpr int kTM = 128;
+constexpr int kMlpThreads = 512;
+constexpr int kMlpWgPerCu = 1;
+#endif
 constexpr int kLDA = 260;                // LDS row stride (floats): 256 + one b128 access of pad
-constexpr int kMlpThreads = 256;         // 4 waves, each 64 rows x 64 cols; two workgroups per CU
 constexpr int kMlpWaves = kMlpThreads / 64;
 constexpr int kMaskWords = (kTM / 32) * (8 / kMlpWaves) * 16 / 32;  // relu-mask words per thread per layer
-constexpr int kMaxMlpGrid = 1024;        // upper bound on persistent workgroups (2 per CU)
+constexpr int kMaxMlpGrid = 1024;        // upper bound on persistent workgroups
 
 // ---- derived sizes -----------------------------------------------------------------
 __host__ __device__ inline int sh_dim(int deg) { return (deg + 1) * (deg + 1); }

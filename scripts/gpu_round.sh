@@ -17,9 +17,9 @@ timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/b
 echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 timeout 200 python bench.py --preset tt --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_tt.json 2> gpurun_out/bench_tt.err
 echo "bench(tt SH25) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_tt.json'));print(round(d['value']),d['ms_per_step'],[(k['kernel'][:14],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"
-if [ -f plenoctree_amd/libplenoctree_hip_v1.so ]; then
-  PXO_LIB=$R/plenoctree_amd/libplenoctree_hip_v1.so timeout 300 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/bench_v1.json 2> gpurun_out/bench_v1.err
-  echo "bench(v1 variant) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_v1.json'));print(d['value'],[(k['kernel'],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"
+if [ -f plenoctree_amd/libplenoctree_hip_g0.so ]; then
+  PXO_LIB=$R/plenoctree_amd/libplenoctree_hip_g0.so timeout 300 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline > gpurun_out/bench_g0.json 2> gpurun_out/bench_g0.err
+  echo "bench(g0 variant) exit $?"; python -c "import json;d=json.load(open('gpurun_out/bench_g0.json'));print(d['value'],[(k['kernel'],round(k['avg_ms'],3),round(k.get('tflops',0),1)) for k in d['kernels']])"
 fi
 if [ "${DO_PROF:-1}" = "1" ]; then
   cd /tmp

@@ -202,30 +202,33 @@ __device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int 
   for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
 }
 
-#ifdef PXO_GEMM_PREFETCH1
-// one k-group of look-ahead for both operands (kgroups even)
-template <int RBN, int CBN>
-__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
-  f32x4 a0[RBN], b0[CBN], a1[RBN], b1[CBN];
-  load_group<RBN, CBN>(arow, wp, 0, kg_stride, a0, b0);
-  for (int g = 0; g < kgroups; g += 2) {
-    load_group<RBN, CBN>(arow, wp, g + 1, kg_stride, a1, b1);
-    mfma_group<RBN, CBN>(a0, b0, acc);
-    const int gn = g + 2 < kgroups ? g + 2 : g;      // harmless re-load on the last trip
-    load_group<RBN, CBN>(arow, wp, gn, kg_stride, a0, b0);
-    mfma_group<RBN, CBN>(a1, b1, acc);
-  }
-}
-#else
 // B (weights, L2 latency) is fetched two k-groups ahead into four rotating register sets, A (LDS)
 // one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
 // sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
 // each load to just before its use and exposes the LDS/L2 latency on every k-group.
 #define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
-template <int RBN, int CBN>
+// A "side job" rides along the k-groups: the copy of the previous layer's finished LDS tile to HBM is
+// cut into pieces (one 16 B load + store per thread) issued one per k-group slot, so the stores
+// trickle out under the MFMAs instead of bursting at the ~13 B/clk/CU store-issue limit between
+// layers (measured: 10 % of the kernel before this).
+struct NoSide { __device__ __forceinline__ void operator()(int) {} };
+
+struct TileStoreSide {          // piece p: LDS read in slot 2p, global store in slot 2p+1
+  const float* lds; float* dst; int64_t row0, M; bool full; int tid; f32x4 hold;
+  __device__ __forceinline__ void operator()(int g) {
+    constexpr int kPieces = kTM * kW / 4 / kMlpThreads;
+    const int p = g >> 1;
+    if (p >= kPieces) return;
+    const int idx = tid + kMlpThreads * p;
+    const int row = idx >> 6, c4 = idx & 63;
+    if ((g & 1) == 0) hold = *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+    else if (full || row0 + row < M) *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) = hold;
+  }
+};
+
+template <int RBN, int CBN, class Side>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side) {
   f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
   const int last = kgroups - 1;
   load_b<CBN>(wp, 0, kg_stride, b0);
@@ -234,27 +237,59 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
   for (int g = 0; g < kgroups; g += 4) {
     load_a<RBN>(arow, g + 1, a1);
     load_b<CBN>(wp, g + 2, kg_stride, b2);
+    side(g);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b0, acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 2, a0);
     load_b<CBN>(wp, g + 3, kg_stride, b3);
+    side(g + 1);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b1, acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 3, a1);
     load_b<CBN>(wp, g + 4 < last ? g + 4 : last, kg_stride, b0);    // harmless re-load on the last trip
+    side(g + 2);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b2, acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 4 < last ? g + 4 : last, a0);
     load_b<CBN>(wp, g + 5 < last ? g + 5 : last, kg_stride, b1);
+    side(g + 3);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b3, acc);
     PXO_PIN();
   }
 }
-#endif
+template <int RBN, int CBN>
+__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
+  NoSide none;
+  gemm_lds_packed<RBN, CBN, NoSide>(arow, wp, kgroups, kg_stride, acc, none);
+}
+
+// head GEMM: one row block, CBN column blocks `cb_stride` f32x4 apart, 32 k-groups, pipelined like the trunk
+template <int CBN, class Side>
+__device__ __forceinline__ void gemm_head(const float* __restrict__ arow, const f32x4* __restrict__ wp, int cb_stride,
+                                          int kg_stride, f32x16 (&acc)[1][CBN], Side& side) {
+  f32x4 a0[1], a1[1], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
+  auto lb = [&](int g, f32x4 (&b)[CBN]) {
+#pragma unroll
+    for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * cb_stride];
+  };
+  lb(0, b0); lb(1, b1);
+  load_a<1>(arow, 0, a0);
+  for (int g = 0; g < 32; g += 4) {
+    load_a<1>(arow, g + 1, a1); lb(g + 2, b2); side(g); PXO_PIN();
+    mfma_group<1, CBN>(a0, b0, acc); PXO_PIN();
+    load_a<1>(arow, g + 2, a0); lb(g + 3, b3); side(g + 1); PXO_PIN();
+    mfma_group<1, CBN>(a1, b1, acc); PXO_PIN();
+    load_a<1>(arow, g + 3, a1); lb(g + 4 < 31 ? g + 4 : 31, b0); side(g + 2); PXO_PIN();
+    mfma_group<1, CBN>(a0, b2, acc); PXO_PIN();
+    load_a<1>(arow, g + 4 < 31 ? g + 4 : 31, a0); lb(g + 5 < 31 ? g + 5 : 31, b1); side(g + 3); PXO_PIN();
+    mfma_group<1, CBN>(a1, b3, acc); PXO_PIN();
+  }
+}
 
 template <int RBN, int CBN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {
@@ -285,6 +320,21 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
 constexpr int kRB = kTM / 32;                    // row blocks per tile (all owned by every wave)
 constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 256-wide layer
 
+#ifdef PXO_TRACE
+// cycle stamps of wave 0 of workgroup 0 over its first two tiles (timing experiments only)
+__device__ unsigned long long g_trace[512];
+__device__ int g_trace_n;
+#define TRACE(id)                                                                     \
+  do {                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tile >= 10 * (int64_t)gridDim.x && tile < 12 * (int64_t)gridDim.x && g_trace_n < 510) { \
+      g_trace[g_trace_n] = ((unsigned long long)(id) << 48) | (clock64() & 0xFFFFFFFFFFFFull); \
+      g_trace_n++;                                                                    \
+    }                                                                                 \
+  } while (0)
+#else
+#define TRACE(id)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -305,8 +355,10 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
     const int64_t row0 = tile * kTM;
     const bool full = row0 + kTM <= M;
     __syncthreads();   // previous tile's head GEMM has consumed the LDS tile
+    TRACE(1);
     posenc_tile(lds, pts, grid, row0, M, tid);
     __syncthreads();
+    TRACE(2);
     if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
 #pragma unroll
       for (int i = 0; i < kTM * kEncPad / 4 / kMlpThreads; ++i) {
@@ -319,13 +371,22 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
     }
 
     f32x16 acc[kRB][kCB];
+    // copy of the previous layer's tile to `acts`, issued piecewise inside the running GEMM
+    TileStoreSide side{lds, acts, row0, M, full, tid, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int l = 0; l < kDepth; ++l) {
       zero_acc(acc);
       float bl[kCB];                       // this layer's biases, fetched under the GEMM
 #pragma unroll
       for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
-      gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+      TRACE(10 + l);
+      if (SAVE && l > 0) {
+        side.dst = acts + (int64_t)(l - 1) * M * kW;
+        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
+      } else {
+        gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+      }
+      TRACE(20 + l);
       if (l == 5) {
         // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
         // columns are a second K segment; the encoding is recomputed into the consumed tile.
@@ -343,7 +404,9 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
         for (int c = 0; c < kCB; ++c) asm volatile("" ::"v"(acc[r][c]));
       continue;
 #endif
+      TRACE(30 + l);
       __syncthreads();  // every wave has consumed the input tile
+      TRACE(40 + l);
       // re-derive the lane ids from an opaque copy so that the epilogue / store addresses are
       // computed here instead of being hoisted out of the loops into (scarce) registers
       int tid_e = tid;
@@ -378,10 +441,10 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
 #else
       asm volatile("" ::"v"(mw[0]), "v"(mw[kMaskWords - 1]));
 #endif
+      TRACE(50 + l);
       __syncthreads();
-#if !defined(PXO_ABLATE)
-      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
-#endif
+      TRACE(60 + l);
+      TRACE(70 + l);
     }
 
     // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
@@ -390,25 +453,22 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       constexpr int CSTEP = kMlpWaves / kRB;               // waves sharing a row block
       constexpr int HMAX = (NHB + CSTEP - 1) / CSTEP;
       const int rb = wave % kRB, cb0 = wave / kRB;
-      f32x16 hacc[HMAX];
-#pragma unroll
-      for (int i = 0; i < HMAX; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) hacc[i][e] = 0.f;
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + lane;
+      f32x16 hacc[1][HMAX];
+      zero_acc(hacc);
+      // column blocks cb0, cb0+CSTEP, ...; a block past NHB is clamped (computed twice, stored once)
+      const int cbl = cb0 + (HMAX - 1) * CSTEP < NHB ? CSTEP : 0;
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + cb0 * 64 + lane;
       const float* ar = arow + rb * 32 * kLDA;
-      for (int g = 0; g < 32; ++g) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ar + g * 8);
-#pragma unroll
-        for (int i = 0; i < HMAX; ++i) {
-          const int cb = cb0 + i * CSTEP;
-          if (cb < NHB) {
-            const f32x4 b = wp[((int64_t)g * NHB + cb) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], hacc[i], 0, 0, 0);
-          }
-        }
+      // same pipelined loop as the trunk (CBN column blocks `cbl*64` f32x4 apart); layer 7's tile goes
+      // out to `acts` underneath it
+      if (SAVE) {
+        side.dst = acts + (int64_t)(kDepth - 1) * M * kW;
+        gemm_head<HMAX, TileStoreSide>(ar, wp, cbl * 64, NHB * 64, hacc, side);
+      } else {
+        NoSide none;
+        gemm_head<HMAX, NoSide>(ar, wp, cbl * 64, NHB * 64, hacc, none);
       }
+      TRACE(90);
       const float* hb = bias + 8 * kW;
 #pragma unroll
       for (int i = 0; i < HMAX; ++i) {
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
           for (int reg = 0; reg < 16; ++reg) {
             const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
             if (grow < M) {
-              const float v = hacc[i][reg] + b;
+              const float v = hacc[0][i][reg] + b;
               if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
               else if (col == C) raw_sigma[grow] = v;
             }
@@ -556,14 +616,17 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
         if (lane_e < 32) my_db[l * kW + col] += colsum;
       }
       __syncthreads();
-      store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
       if (l > 0) {
         zero_acc(acc);
         const uint32_t* mp = mask + ((tile * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
-        gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
+        // dz_l leaves for HBM piecewise underneath the GEMM that consumes it
+        TileStoreSide side{lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e, f32x4{0.f, 0.f, 0.f, 0.f}};
+        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
+      } else {
+        store_tile(lds, dz, row0, M, full, tid_e);
       }
     }
   }
@@ -597,5 +660,17 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
   }
   return check_launch("mlp_bwd_data");
 }
+
+#ifdef PXO_TRACE
+extern "C" int pxo_debug_trace(unsigned long long* out, int cap, int reset) {
+  int n = 0;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(int));
+  if (n > cap) n = cap;
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n);
+  if (reset) { int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &z, sizeof(int)); }
+  return n;
+}
+#endif
 
 }  // namespace pxo

@@ -226,35 +226,58 @@ struct TileStoreSide {          // piece p: LDS read in slot 2p, global store in
   }
 };
 
+#ifndef PXO_BDIST
+#define PXO_BDIST 3      // k-groups of look-ahead for the weight fragments (2 or 3; four register sets either way)
+#endif
 template <int RBN, int CBN, class Side>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side) {
   f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
   const int last = kgroups - 1;
+  auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
   load_b<CBN>(wp, 0, kg_stride, b0);
   load_b<CBN>(wp, 1, kg_stride, b1);
+#if PXO_BDIST == 3
+  load_b<CBN>(wp, cl(2), kg_stride, b2);
+#endif
   load_a<RBN>(arow, 0, a0);
   for (int g = 0; g < kgroups; g += 4) {
     load_a<RBN>(arow, g + 1, a1);
+#if PXO_BDIST == 3
+    load_b<CBN>(wp, cl(g + 3), kg_stride, b3);
+#else
     load_b<CBN>(wp, g + 2, kg_stride, b2);
+#endif
     side(g);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b0, acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 2, a0);
+#if PXO_BDIST == 3
+    load_b<CBN>(wp, cl(g + 4), kg_stride, b0);
+#else
     load_b<CBN>(wp, g + 3, kg_stride, b3);
+#endif
     side(g + 1);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b1, acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 3, a1);
-    load_b<CBN>(wp, g + 4 < last ? g + 4 : last, kg_stride, b0);    // harmless re-load on the last trip
+#if PXO_BDIST == 3
+    load_b<CBN>(wp, cl(g + 5), kg_stride, b1);
+#else
+    load_b<CBN>(wp, cl(g + 4), kg_stride, b0);
+#endif
     side(g + 2);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b2, acc);
     PXO_PIN();
-    load_a<RBN>(arow, g + 4 < last ? g + 4 : last, a0);
-    load_b<CBN>(wp, g + 5 < last ? g + 5 : last, kg_stride, b1);
+    load_a<RBN>(arow, cl(g + 4), a0);
+#if PXO_BDIST == 3
+    load_b<CBN>(wp, cl(g + 6), kg_stride, b2);
+#else
+    load_b<CBN>(wp, cl(g + 5), kg_stride, b1);
+#endif
     side(g + 3);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b3, acc);
@@ -311,9 +334,14 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
   for (int i = 0; i < kTM * kW / 4 / kMlpThreads; ++i) {
     const int idx = tid + kMlpThreads * i;
     const int row = idx >> 6, c4 = idx & 63;
-    if (full || row0 + row < M)
-      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) =
-          *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+    if (full || row0 + row < M) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+#ifdef PXO_NT_STORE
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4));
+#else
+      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) = v;
+#endif
+    }
   }
 }
 
@@ -380,7 +408,11 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
       TRACE(10 + l);
-      if (SAVE && l > 0) {
+#ifndef PXO_SIDE
+#define PXO_SIDE 0   // 1: trickle the tile stores through the next GEMM -- measured slower (in-order vmcnt couples
+                     // the stores to the weight-fragment waits): 142.3k vs 149.5k rays/s
+#endif
+      if (PXO_SIDE && SAVE && l > 0) {
         side.dst = acts + (int64_t)(l - 1) * M * kW;
         gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
       } else {
@@ -444,6 +476,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       TRACE(50 + l);
       __syncthreads();
       TRACE(60 + l);
+      if (SAVE && (!PXO_SIDE || l == kDepth - 1)) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
       TRACE(70 + l);
     }
 
@@ -461,13 +494,8 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       const float* ar = arow + rb * 32 * kLDA;
       // same pipelined loop as the trunk (CBN column blocks `cbl*64` f32x4 apart); layer 7's tile goes
       // out to `acts` underneath it
-      if (SAVE) {
-        side.dst = acts + (int64_t)(kDepth - 1) * M * kW;
-        gemm_head<HMAX, TileStoreSide>(ar, wp, cbl * 64, NHB * 64, hacc, side);
-      } else {
-        NoSide none;
-        gemm_head<HMAX, NoSide>(ar, wp, cbl * 64, NHB * 64, hacc, none);
-      }
+      NoSide none;
+      gemm_head<HMAX, NoSide>(ar, wp, cbl * 64, NHB * 64, hacc, none);
       TRACE(90);
       const float* hb = bias + 8 * kW;
 #pragma unroll
@@ -623,8 +651,13 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
         for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
         // dz_l leaves for HBM piecewise underneath the GEMM that consumes it
+#if PXO_SIDE
         TileStoreSide side{lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e, f32x4{0.f, 0.f, 0.f, 0.f}};
         gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
+#else
+        store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
+        gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
+#endif
       } else {
         store_tile(lds, dz, row0, M, full, tid_e);
       }

@@ -99,6 +99,17 @@ def cpu_baseline(args_ns, n_rays, n_steps):
                       f"{sum(times):.1f} s"}
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (profiles/hbm_traffic.json; rocprofv3 cannot run inside the timed process).  None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"][kernel]
+        return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,7 +199,7 @@ def main():
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "flop_per_launch": dom["rows_per_launch"] * FLOP_FWD_PER_ROW[deg],
-                        "traffic": None}
+                        "traffic": hbm_traffic("mlp_fwd_kernel")}
         out = {
             "metric": "training rays/sec (800x800, 64+128 samples)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

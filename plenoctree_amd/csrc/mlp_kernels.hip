@@ -182,15 +182,6 @@ __device__ __forceinline__ void mfma_group(const f32x4 (&a)[RBN], const f32x4 (&
         acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
 }
 
-template <int RBN, int CBN>
-__device__ __forceinline__ void load_group(const float* __restrict__ arow, const f32x4* __restrict__ wp, int g,
-                                           int kg_stride, f32x4 (&a)[RBN], f32x4 (&b)[CBN]) {
-#pragma unroll
-  for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
-#pragma unroll
-  for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + g * 8);
-}
-
 template <int RBN>
 __device__ __forceinline__ void load_a(const float* __restrict__ arow, int g, f32x4 (&a)[RBN]) {
 #pragma unroll
@@ -327,21 +318,18 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {
 // accumulator register `reg` of a 32x32 tile holds row (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// coalesced copy of the finished kTM x 256 LDS tile to a row-major [M,256] global array
+// coalesced copy of the finished kTM x 256 LDS tile to a row-major [M,256] global array (whole 1 KiB
+// rows per wave instruction).  Tried and measured no better: only half of the waves copying while the
+// others start the next GEMM, non-temporal stores, and trickling the copy through the next GEMM.
 __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
                                            int64_t M, bool full, int tid) {
 #pragma unroll
   for (int i = 0; i < kTM * kW / 4 / kMlpThreads; ++i) {
     const int idx = tid + kMlpThreads * i;
     const int row = idx >> 6, c4 = idx & 63;
-    if (full || row0 + row < M) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
-#ifdef PXO_NT_STORE
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4));
-#else
-      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) = v;
-#endif
-    }
+    if (full || row0 + row < M)
+      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
   }
 }
 

@@ -139,8 +139,6 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
                            size_t ws_bytes, hipStream_t s);
 int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
-int launch_grid_points(int reso, int x0, int x1, const float* off_scale /*6 floats, device*/,
-                       float* pts, hipStream_t s);
 
 int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_,
                              float far_, int lindisp, const float* t_rand, float* z, float* pts,

@@ -673,3 +673,67 @@ def test_trained_psnr_matches_oracle_training():
                     '"psnr_hip_trained": %.4f}\n' % (steps, B, psnr_init, psnr_ref, psnr_hip))
     assert abs(psnr_hip - psnr_ref) <= 0.1, (psnr_hip, psnr_ref)
     assert psnr_hip > psnr_init + 0.1, (psnr_hip, psnr_init)     # and training made progress (short run)
+
+
+@pytest.mark.parametrize("N", [1, 63, 127, 128, 129, 1000])
+def test_eval_points_ragged_sizes(N):
+    """Tile tails: every size around the 64/128-row tile boundary gives the same rows as a padded batch."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)
+    flat = make_params(cfg)
+    pf, _ = ops.pack_weights(pcfg, split_mlp(flat, cfg, 1).to(dev), need_bwd=False)
+    pts = (torch.rand(1024, 3, generator=torch.Generator().manual_seed(N)) * 2 - 1) * 2.0
+    full_rgb, full_sig = ops.eval_points(pcfg, pf, pts.to(dev))
+    rgb, sig = ops.eval_points(pcfg, pf, pts[:N].contiguous().to(dev))
+    assert rgb.shape == (N, 48) and sig.shape == (N, 1)
+    assert torch.equal(rgb, full_rgb[:N]) and torch.equal(sig, full_sig[:N])     # row-independent, bit-exact
+
+
+@pytest.mark.parametrize("deg,B", [(0, 5), (1, 3), (2, 1), (4, 2)])
+def test_train_step_small_and_all_degrees(deg, B):
+    """Every SH degree the reference supports (nerf_sh/nerf/sh.py:69) through the whole train step, with
+    tiny / odd ray counts (partial tiles in every kernel)."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg, sparsity_npoints=50)
+    pcfg = pxo_cfg(ops, cfg)
+    flat = make_params(cfg, bias_scale=0.2)
+    rays = make_rays(B, 71 + deg)
+    gen = torch.Generator().manual_seed(73)
+    px = torch.rand(B, 3, generator=gen)
+    t_rand = torch.rand(B, 64, generator=gen); u = torch.rand(B, 128, generator=gen)
+    sp = (torch.rand(50, 3, generator=gen) * 2 - 1) * 1.5
+    fd = flat.to(dev)
+    packed = [ops.pack_weights(pcfg, split_mlp(fd, cfg, i)) for i in range(2)]
+    grads = torch.full_like(fd, float("nan")); stats = torch.zeros(6, device=dev)
+    ws = torch.empty(ops.train_workspace_bytes(pcfg, B), dtype=torch.uint8, device=dev)
+    ops.train_fwd_bwd(pcfg, fd, packed, rays.origins.to(dev), rays.directions.to(dev), rays.viewdirs.to(dev),
+                      px.to(dev), grads, stats, ws, randomized=True, t_rand=t_rand.to(dev), u=u.to(dev),
+                      sp_points=sp.to(dev))
+    total, st, g_ref = O.loss_and_grad(flat, rays, px, cfg, t_rand, u, sp)
+    for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
+        close(f"stats/{k}", stats.cpu()[i], st[k].float(), rtol=5e-5, atol=1e-6)
+    assert float(g_ref.norm()) > 0
+    rel = float((grads.cpu().double() - g_ref.double()).norm() / g_ref.double().norm())
+    assert rel < 2e-3, f"gradient relative L2 error {rel}"      # kink-flip bound, see the larger test
+
+
+def test_error_paths_on_device():
+    """C-ABI error behaviour: bad sizes / missing buffers return codes and messages, nothing launches."""
+    ops = _ops(); dev = _gpu()
+    from plenoctree_amd import _lib
+    cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)
+    z = torch.zeros(4, 300, device=dev)
+    with pytest.raises(_lib.PxoError, match="samples per ray"):
+        ops.shade_composite_fwd(pcfg, torch.zeros(1200, 48, device=dev), torch.zeros(1200, device=dev), z,
+                                torch.ones(4, 3, device=dev), torch.ones(4, 3, device=dev))
+    with pytest.raises(_lib.PxoError, match="sample_pdf"):
+        ops.sample_pdf(torch.zeros(4, 2, device=dev), torch.zeros(4, 2, device=dev), torch.zeros(4, 3, device=dev),
+                       torch.ones(4, 3, device=dev), 8)
+    with pytest.raises(_lib.PxoError, match="workspace"):
+        flat = make_params(cfg).to(dev)
+        packed = [ops.pack_weights(pcfg, split_mlp(flat, cfg, i)) for i in range(2)]
+        ops.train_fwd_bwd(pcfg, flat, packed, torch.zeros(8, 3, device=dev), torch.ones(8, 3, device=dev),
+                          torch.ones(8, 3, device=dev), torch.zeros(8, 3, device=dev), torch.zeros_like(flat),
+                          torch.zeros(6, device=dev), torch.empty(1024, dtype=torch.uint8, device=dev))
+    with pytest.raises(_lib.PxoError):
+        ops.posenc(torch.zeros(4, 3))          # host tensor

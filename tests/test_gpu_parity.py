@@ -711,7 +711,8 @@ def test_train_step_small_and_all_degrees(deg, B):
                       sp_points=sp.to(dev))
     total, st, g_ref = O.loss_and_grad(flat, rays, px, cfg, t_rand, u, sp)
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
-        close(f"stats/{k}", stats.cpu()[i], st[k].float(), rtol=5e-5, atol=1e-6)
+        close(f"stats/{k}", stats.cpu()[i], st[k].float(), rtol=3e-4, atol=2e-6)   # few rays: no averaging of the
+        # ill-conditioned fine samples (see test_sample_pdf)
     assert float(g_ref.norm()) > 0
     rel = float((grads.cpu().double() - g_ref.double()).norm() / g_ref.double().norm())
     assert rel < 2e-3, f"gradient relative L2 error {rel}"      # kink-flip bound, see the larger test

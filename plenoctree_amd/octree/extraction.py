@@ -10,6 +10,7 @@ sigma mask, which is exactly what the tree-building stage consumes.
     python -m torch.distributed.run --nproc-per-node 8 -m plenoctree_amd.octree.extraction ...
 """
 import sys
+import time
 
 import numpy as np
 import torch
@@ -102,7 +103,15 @@ def main(argv=None):
     reso = 2 ** (args.init_grid_depth + 1)
     if comm.rank == 0:
         print("* Step 1: Grid eval", reso, flush=True)
+    torch.cuda.synchronize(); comm.barrier()
+    t0 = time.time()
     sig = grid_sigma(model, state, reso, center, radius, comm)
+    torch.cuda.synchronize(); comm.barrier()
+    dt = time.time() - t0
+    if comm.rank == 0:
+        flop = reso ** 3 * (1007104 if model.sh_deg == 3 else 1020928)
+        print(f"* grid eval: {reso ** 3} points in {dt:.3f} s = {reso ** 3 / dt / 1e6:.1f} Mpts/s "
+              f"({flop / dt / 1e12:.1f} TFLOP/s over {comm.world} GPU(s))", flush=True)
     sigma_thresh = -np.log(1.0 - args.alpha_thresh) / (2.0 / reso)
     mask = sig >= sigma_thresh
     if comm.rank == 0:

@@ -67,6 +67,9 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--variants" in sys.argv:   # previous-generation inner loops, for in-session A/B runs
         build(suffix="_g0", extra_flags=("-DPXO_GEOM=0",))      # 64-row tiles, two workgroups per CU
+    if "--wgrad-variants" in sys.argv:
+        for v in (1, 2, 3, 4):
+            build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))
     if "--trace" in sys.argv:      # cycle-stamped forward kernel (timing experiment)
         build(suffix="_trace_g1", extra_flags=("-DPXO_TRACE", "-DPXO_GEOM=1"))
         build(suffix="_trace_g0", extra_flags=("-DPXO_TRACE", "-DPXO_GEOM=0"))

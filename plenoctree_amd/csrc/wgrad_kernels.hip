@@ -283,8 +283,20 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   for (int l = 1; l < kDepth; ++l) {
     {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
-#ifdef PXO_WGRAD_V1
+#ifndef PXO_WGRAD_VARIANT
+#define PXO_WGRAD_VARIANT 0
+#endif
+#if PXO_WGRAD_VARIANT == 1     // one 8-wave workgroup per CU, 32-row chunks, no column split
     hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 2, false, 512, 32, 1>), dim3(P), dim3(512), 0, s,
+                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
+#elif PXO_WGRAD_VARIANT == 2   // 4-way column split: 256 x 64 per workgroup, up to 4 workgroups per CU
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 4>), dim3(((P + 7) / 8) * 32), dim3(256), 0, s,
+                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
+#elif PXO_WGRAD_VARIANT == 3   // 2-way split, waves tiled 4 x 1 (64 rows x 128 cols each)
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 1, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
+                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
+#elif PXO_WGRAD_VARIANT == 4   // 2-way split, 32-row chunks (one workgroup per CU by LDS)
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 32, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
                        acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
 #else
     // 256x256 product as two independent 4-wave workgroups per CU (256 x 128 each, 16-row chunks)

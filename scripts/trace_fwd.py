@@ -3,11 +3,11 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plenoctree_amd import _lib, ops
-from oracle import nerf_oracle as O
+from plenoctree_amd.nerf_sh.nerf import models
 lib = _lib.load()
 dev = torch.device("cuda:0")
 cfg = ops.make_cfg()
-flat = O.flatten_params(O.init_params(O.Cfg()))
+flat = models.init_params(cfg)
 n = flat.numel() // 2
 pf, _ = ops.pack_weights(cfg, flat[n:].contiguous().to(dev), need_bwd=False)
 M = 4096 * 192 + 10000

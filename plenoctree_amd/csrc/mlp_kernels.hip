@@ -220,34 +220,17 @@ struct TileStoreSide {          // piece p: LDS read in slot 2p, global store in
 #ifndef PXO_BDIST
 #define PXO_BDIST 3      // k-groups of look-ahead for the weight fragments (2 or 3; four register sets either way)
 #endif
-// The first PXO_BDIST weight fragments of a GEMM, fetched ahead of time (before the previous layer's
-// epilogue and tile store): gfx950 has one in-order vmcnt, so fragments issued *after* the store burst
-// could only be waited for together with all those stores -- the GEMM start then idled until the
-// stores had drained.
-template <int CBN>
-struct BSets { f32x4 b0[CBN], b1[CBN], b2[CBN]; };
-
-template <int CBN>
-__device__ __forceinline__ void prefetch_b(const f32x4* __restrict__ wp, int kgroups, int kg_stride, BSets<CBN>& p) {
-  const int last = kgroups - 1;
-  load_b<CBN>(wp, 0, kg_stride, p.b0);
-  load_b<CBN>(wp, 1, kg_stride, p.b1);
-#if PXO_BDIST == 3
-  load_b<CBN>(wp, 2 < last ? 2 : last, kg_stride, p.b2);
-#endif
-  PXO_PIN();
-}
-
 template <int RBN, int CBN, class Side>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side,
-                                                BSets<CBN>& pre) {
-  f32x4 a0[RBN], a1[RBN], b3[CBN];
-  f32x4 (&b0)[CBN] = pre.b0;
-  f32x4 (&b1)[CBN] = pre.b1;
-  f32x4 (&b2)[CBN] = pre.b2;
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side) {
+  f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
   const int last = kgroups - 1;
   auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
+  load_b<CBN>(wp, 0, kg_stride, b0);
+  load_b<CBN>(wp, 1, kg_stride, b1);
+#if PXO_BDIST == 3
+  load_b<CBN>(wp, cl(2), kg_stride, b2);
+#endif
   load_a<RBN>(arow, 0, a0);
   for (int g = 0; g < kgroups; g += 4) {
     load_a<RBN>(arow, g + 1, a1);
@@ -291,13 +274,6 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
     mfma_group<RBN, CBN>(a1, b3, acc);
     PXO_PIN();
   }
-}
-template <int RBN, int CBN, class Side>
-__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side) {
-  BSets<CBN> pre;
-  prefetch_b<CBN>(wp, kgroups, kg_stride, pre);
-  gemm_lds_packed<RBN, CBN, Side>(arow, wp, kgroups, kg_stride, acc, side, pre);
 }
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
@@ -364,17 +340,14 @@ constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 
 // cycle stamps of wave 0 of workgroup 0 over its first two tiles (timing experiments only)
 __device__ unsigned long long g_trace[512];
 __device__ int g_trace_n;
-#define TRACE_INIT() int trace_i = 0
 #define TRACE(id)                                                                     \
   do {                                                                                \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && tile >= 10 * (int64_t)gridDim.x &&      \
-        tile < 12 * (int64_t)gridDim.x && trace_i < 510) {                            \
-      g_trace[trace_i++] = ((unsigned long long)(id) << 48) | (clock64() & 0xFFFFFFFFFFFFull); \
-      g_trace_n = trace_i;                                                            \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tile >= 10 * (int64_t)gridDim.x && tile < 12 * (int64_t)gridDim.x && g_trace_n < 510) { \
+      g_trace[g_trace_n] = ((unsigned long long)(id) << 48) | (clock64() & 0xFFFFFFFFFFFFull); \
+      g_trace_n++;                                                                    \
     }                                                                                 \
   } while (0)
 #else
-#define TRACE_INIT()
 #define TRACE(id)
 #endif
 
@@ -393,7 +366,6 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
   const int64_t ntiles = num_tiles(M);
-  TRACE_INIT();
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * kTM;
@@ -415,7 +387,8 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
     }
 
     f32x16 acc[kRB][kCB];
-    BSets<kCB> pre;            // first weight fragments of the upcoming trunk GEMM
+    // copy of the previous layer's tile to `acts`, issued piecewise inside the running GEMM
+    TileStoreSide side{lds, acts, row0, M, full, tid, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int l = 0; l < kDepth; ++l) {
       zero_acc(acc);
       float bl[kCB];                       // this layer's biases, fetched under the GEMM
@@ -423,10 +396,15 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
       TRACE(10 + l);
-      {
-        NoSide none;
-        if (l == 0) prefetch_b<kCB>(wp, 8, 8 * 64, pre);       // (layers > 0: fetched before the previous epilogue)
-        gemm_lds_packed<kRB, kCB, NoSide>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, none, pre);
+#ifndef PXO_SIDE
+#define PXO_SIDE 0   // 1: trickle the tile stores through the next GEMM -- measured slower (in-order vmcnt couples
+                     // the stores to the weight-fragment waits): 142.3k vs 149.5k rays/s
+#endif
+      if (PXO_SIDE && SAVE && l > 0) {
+        side.dst = acts + (int64_t)(l - 1) * M * kW;
+        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
+      } else {
+        gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
       }
       TRACE(20 + l);
       if (l == 5) {
@@ -446,10 +424,6 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
         for (int c = 0; c < kCB; ++c) asm volatile("" ::"v"(acc[r][c]));
       continue;
 #endif
-      if (l + 1 < kDepth) {      // next layer's first fragments go out before the epilogue and the tile store
-        const f32x4* wn = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l + 1)) + (wave * kCB) * 64 + lane;
-        prefetch_b<kCB>(wn, 32, 8 * 64, pre);
-      }
       TRACE(30 + l);
       __syncthreads();  // every wave has consumed the input tile
       TRACE(40 + l);
@@ -490,7 +464,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       TRACE(50 + l);
       __syncthreads();
       TRACE(60 + l);
-      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
+      if (SAVE && (!PXO_SIDE || l == kDepth - 1)) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
       TRACE(70 + l);
     }
 
@@ -635,12 +609,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
       gemm_lds_packed<kRB, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
     }
-    BSets<kCB> pre;
     for (int l = kDepth - 1; l >= 0; --l) {
-      if (l > 0) {               // weight fragments of the GEMM that follows this epilogue
-        const f32x4* wn = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
-        prefetch_b<kCB>(wn, 32, 8 * 64, pre);
-      }
       __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
       int tid_e = tid;
       asm volatile("" : "+v"(tid_e));   // see mlp_fwd_kernel: keeps the epilogue addresses out of the loops' live set
@@ -669,9 +638,14 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
+        // dz_l leaves for HBM piecewise underneath the GEMM that consumes it
+#if PXO_SIDE
+        TileStoreSide side{lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e, f32x4{0.f, 0.f, 0.f, 0.f}};
+        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
+#else
         store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
-        NoSide none;
-        gemm_lds_packed<kRB, kCB, NoSide>(arow, wp, 32, 8 * 64, acc, none, pre);   // fragments fetched before the epilogue
+        gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
+#endif
       } else {
         store_tile(lds, dz, row0, M, full, tid_e);
       }

@@ -198,31 +198,9 @@ __device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int 
 // sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
 // each load to just before its use and exposes the LDS/L2 latency on every k-group.
 #define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
-// A "side job" rides along the k-groups: the copy of the previous layer's finished LDS tile to HBM is
-// cut into pieces (one 16 B load + store per thread) issued one per k-group slot, so the stores
-// trickle out under the MFMAs instead of bursting at the ~13 B/clk/CU store-issue limit between
-// layers (measured: 10 % of the kernel before this).
-struct NoSide { __device__ __forceinline__ void operator()(int) {} };
-
-struct TileStoreSide {          // piece p: LDS read in slot 2p, global store in slot 2p+1
-  const float* lds; float* dst; int64_t row0, M; bool full; int tid; f32x4 hold;
-  __device__ __forceinline__ void operator()(int g) {
-    constexpr int kPieces = kTM * kW / 4 / kMlpThreads;
-    const int p = g >> 1;
-    if (p >= kPieces) return;
-    const int idx = tid + kMlpThreads * p;
-    const int row = idx >> 6, c4 = idx & 63;
-    if ((g & 1) == 0) hold = *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
-    else if (full || row0 + row < M) *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) = hold;
-  }
-};
-
-#ifndef PXO_BDIST
-#define PXO_BDIST 3      // k-groups of look-ahead for the weight fragments (2 or 3; four register sets either way)
-#endif
-template <int RBN, int CBN, class Side>
+template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN], Side& side) {
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
   f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
   const int last = kgroups - 1;
   auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
@@ -239,7 +217,6 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
 #else
     load_b<CBN>(wp, g + 2, kg_stride, b2);
 #endif
-    side(g);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b0, acc);
     PXO_PIN();
@@ -249,7 +226,6 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
 #else
     load_b<CBN>(wp, g + 3, kg_stride, b3);
 #endif
-    side(g + 1);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b1, acc);
     PXO_PIN();
@@ -259,7 +235,6 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
 #else
     load_b<CBN>(wp, cl(g + 4), kg_stride, b0);
 #endif
-    side(g + 2);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b2, acc);
     PXO_PIN();
@@ -269,23 +244,16 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
 #else
     load_b<CBN>(wp, cl(g + 5), kg_stride, b1);
 #endif
-    side(g + 3);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b3, acc);
     PXO_PIN();
   }
 }
-template <int RBN, int CBN>
-__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
-  NoSide none;
-  gemm_lds_packed<RBN, CBN, NoSide>(arow, wp, kgroups, kg_stride, acc, none);
-}
 
 // head GEMM: one row block, CBN column blocks `cb_stride` f32x4 apart, 32 k-groups, pipelined like the trunk
-template <int CBN, class Side>
+template <int CBN>
 __device__ __forceinline__ void gemm_head(const float* __restrict__ arow, const f32x4* __restrict__ wp, int cb_stride,
-                                          int kg_stride, f32x16 (&acc)[1][CBN], Side& side) {
+                                          int kg_stride, f32x16 (&acc)[1][CBN]) {
   f32x4 a0[1], a1[1], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
   auto lb = [&](int g, f32x4 (&b)[CBN]) {
 #pragma unroll
@@ -294,13 +262,13 @@ __device__ __forceinline__ void gemm_head(const float* __restrict__ arow, const 
   lb(0, b0); lb(1, b1);
   load_a<1>(arow, 0, a0);
   for (int g = 0; g < 32; g += 4) {
-    load_a<1>(arow, g + 1, a1); lb(g + 2, b2); side(g); PXO_PIN();
+    load_a<1>(arow, g + 1, a1); lb(g + 2, b2); PXO_PIN();
     mfma_group<1, CBN>(a0, b0, acc); PXO_PIN();
-    load_a<1>(arow, g + 2, a0); lb(g + 3, b3); side(g + 1); PXO_PIN();
+    load_a<1>(arow, g + 2, a0); lb(g + 3, b3); PXO_PIN();
     mfma_group<1, CBN>(a1, b1, acc); PXO_PIN();
-    load_a<1>(arow, g + 3, a1); lb(g + 4 < 31 ? g + 4 : 31, b0); side(g + 2); PXO_PIN();
+    load_a<1>(arow, g + 3, a1); lb(g + 4 < 31 ? g + 4 : 31, b0); PXO_PIN();
     mfma_group<1, CBN>(a0, b2, acc); PXO_PIN();
-    load_a<1>(arow, g + 4 < 31 ? g + 4 : 31, a0); lb(g + 5 < 31 ? g + 5 : 31, b1); side(g + 3); PXO_PIN();
+    load_a<1>(arow, g + 4 < 31 ? g + 4 : 31, a0); lb(g + 5 < 31 ? g + 5 : 31, b1); PXO_PIN();
     mfma_group<1, CBN>(a1, b3, acc); PXO_PIN();
   }
 }
@@ -387,8 +355,6 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
     }
 
     f32x16 acc[kRB][kCB];
-    // copy of the previous layer's tile to `acts`, issued piecewise inside the running GEMM
-    TileStoreSide side{lds, acts, row0, M, full, tid, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int l = 0; l < kDepth; ++l) {
       zero_acc(acc);
       float bl[kCB];                       // this layer's biases, fetched under the GEMM
@@ -396,16 +362,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
       TRACE(10 + l);
-#ifndef PXO_SIDE
-#define PXO_SIDE 0   // 1: trickle the tile stores through the next GEMM -- measured slower (in-order vmcnt couples
-                     // the stores to the weight-fragment waits): 142.3k vs 149.5k rays/s
-#endif
-      if (PXO_SIDE && SAVE && l > 0) {
-        side.dst = acts + (int64_t)(l - 1) * M * kW;
-        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
-      } else {
-        gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
-      }
+      gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
       TRACE(20 + l);
       if (l == 5) {
         // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
@@ -464,7 +421,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       TRACE(50 + l);
       __syncthreads();
       TRACE(60 + l);
-      if (SAVE && (!PXO_SIDE || l == kDepth - 1)) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
+      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
       TRACE(70 + l);
     }
 
@@ -480,10 +437,8 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       const int cbl = cb0 + (HMAX - 1) * CSTEP < NHB ? CSTEP : 0;
       const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + cb0 * 64 + lane;
       const float* ar = arow + rb * 32 * kLDA;
-      // same pipelined loop as the trunk (CBN column blocks `cbl*64` f32x4 apart); layer 7's tile goes
-      // out to `acts` underneath it
-      NoSide none;
-      gemm_head<HMAX, NoSide>(ar, wp, cbl * 64, NHB * 64, hacc, none);
+      // same pipelined loop as the trunk (CBN column blocks `cbl*64` f32x4 apart)
+      gemm_head<HMAX>(ar, wp, cbl * 64, NHB * 64, hacc);
       TRACE(90);
       const float* hb = bias + 8 * kW;
 #pragma unroll
@@ -638,14 +593,8 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
         const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
-        // dz_l leaves for HBM piecewise underneath the GEMM that consumes it
-#if PXO_SIDE
-        TileStoreSide side{lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e, f32x4{0.f, 0.f, 0.f, 0.f}};
-        gemm_lds_packed<kRB, kCB, TileStoreSide>(arow, wp, 32, 8 * 64, acc, side);
-#else
         store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
         gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
-#endif
       } else {
         store_tile(lds, dz, row0, M, full, tid_e);
       }

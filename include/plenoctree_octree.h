@@ -1,0 +1,125 @@
+/*
+ * plenoctree_octree.h -- C ABI of the PlenOctree side of the path on MI355X (gfx950): building the
+ * N3Tree from the dense-grid evaluation, the training-view weight mask, and the octree volume
+ * renderer with its gradient.  Same library (libplenoctree_hip.so) and conventions as
+ * plenoctree_hip.h: extern "C", plain pointers, caller-owned device memory, asynchronous on
+ * `void* stream` unless a host-side result is returned, 0 = ok / negative = error.
+ *
+ * In the reference these operations are calls into the third-party package svox
+ * (svox>=0.2.28, not part of the reference tree); each entry point cites the reference call
+ * site (file:line) whose svox call it replaces.
+ *
+ * N3Tree storage (N = 2), identical to svox's and to the npz keys of octree/compression.py:76-86:
+ *   child        int32 [n, 2,2,2]        index(child node) - n, 0 = leaf
+ *   parent_depth int32 [n, 2]            (packed parent cell index ((p*2+i)*2+j)*2+k, depth)
+ *   data         float [n, 2,2,2, D]     D = 3*basis_dim + 1, rgb SH coefficients channel-major,
+ *                                        last channel sigma
+ *   offset[3], invradius[3]              x_tree = offset + invradius * x_world
+ * Nodes are stored breadth-first: all nodes of depth d before depth d+1, each level ordered by
+ * packed parent cell index (the order svox's refine() produces when whole levels are refined).
+ */
+#ifndef PLENOCTREE_OCTREE_H_
+#define PLENOCTREE_OCTREE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXO_TREE_MAX_DEPTH 10   /* depth_limit <= 10: grid of at most 2048^3 */
+
+/* svox RenderOptions (VolumeRenderer._get_options; octree/extraction.py:184-195). */
+typedef struct PxoRenderOpts {
+  float step_size;              /* --renderer_step_size, octree/nerf/utils.py:211-215 */
+  float background_brightness;  /* 1.0 */
+  float sigma_thresh;           /* 0 exact / 1e-2 fast (eval_octree: fast = not no_early_stop) */
+  float stop_thresh;            /* 0 exact / 1e-2 fast */
+} PxoRenderOpts;
+
+/* Read-only view of a tree for the renderers. */
+typedef struct PxoTree {
+  const int32_t* child;
+  const float* data;
+  int64_t n_internal;
+  int32_t data_dim;             /* 3*basis_dim + 1 */
+  int32_t basis_dim;            /* 1, 4, 9, 16 or 25 (data_format SH<k>) */
+  float offset[3];
+  float invradius[3];
+} PxoTree;
+
+/* Pinhole camera (svox CameraSpec; octree/extraction.py:197-201, octree/nerf/utils.py:473-474).
+ * c2w: device pointer to the first 3 rows of the camera-to-world matrix, 12 floats row-major. */
+typedef struct PxoCamera {
+  const float* c2w;
+  float fx, fy;
+  int32_t width, height;
+} PxoCamera;
+
+/* ---- step 1: mask -> tree  (octree/extraction.py:322-352: mask, `tree[grid].refine()` x depth) ---- */
+
+/* mask[i] = value[i] >= thresh (sigma or grid-weight masking, octree/extraction.py:322-331). */
+int pxo_threshold_mask(const float* value, int64_t n, float thresh, uint8_t* mask, void* stream);
+
+/* Workspace for the occupancy pyramid of a 2^(depth+1) grid. */
+int pxo_tree_workspace_bytes(int depth, size_t* bytes);
+/* Builds the occupancy pyramid of `mask` ([reso^3] bytes, reso = 2^(depth+1), x slowest) in `ws` and
+ * returns on the HOST the number of nodes per depth, level_nodes[0..depth] (level_nodes[0] = 1, the
+ * root).  Synchronises `stream`.  The tree will have sum(level_nodes) nodes. */
+int pxo_tree_count_nodes(const uint8_t* mask, int depth, void* ws, size_t ws_bytes, int64_t* level_nodes,
+                         void* stream);
+/* Writes child [n,8] and parent_depth [n,2] of the tree whose pyramid is in `ws` (after
+ * pxo_tree_count_nodes on the same ws); n = sum(level_nodes). */
+int pxo_tree_build(const void* ws, size_t ws_bytes, int depth, const int64_t* level_nodes, int32_t* child,
+                   int32_t* parent_depth, void* stream);
+
+/* ---- step 2: leaf samples and assignment  (octree/extraction.py:355-394, :503) ---- */
+
+/* tree[inds].sample(S) for the 8 cells of each node in [node0, node0+n_nodes): point (cell c, sample s)
+ * = corner + u * side in tree coordinates, returned in world coordinates ((p - offset) / invradius).
+ * u: [n_nodes*8*S, 3] uniforms in [0,1) (pxo_uniform).  points: [n_nodes*8*S, 3], cells in packed order. */
+int pxo_tree_sample_cells(const int32_t* parent_depth, int64_t node0, int64_t n_nodes, int S, const float* u,
+                          const float offset[3], const float invradius[3], float* points, void* stream);
+/* tree[:, -1:].relu_()  (octree/extraction.py:503): clamps the sigma channel of n_cells cells at 0. */
+int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream);
+
+/* ---- weight mask  (_C.grid_weight_render, octree/extraction.py:181-214) ---- */
+
+/* For each of the n_cams cameras (c2w_all: [n_cams,12] device) and every pixel, marches the ray through
+ * the dense sigma grid [reso^3] and keeps, per voxel, the maximum compositing weight
+ * light * (1 - exp(-dt * sigma)).  grid_weight [reso^3] must be zero-initialised by the caller for the
+ * first call; successive calls accumulate the maximum (torch.max over cameras, :206-212). */
+int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx,
+                           float fy, int width, int height, const PxoRenderOpts* opts, const float offset[3],
+                           const float invradius[3], float* grid_weight, void* stream);
+
+/* ---- octree volume renderer  (VolumeRenderer.render_persp / render; octree/nerf/utils.py:456-474,
+ *      octree/optimization.py:174-216) ---- */
+
+/* Forward.  Rays come either from `cam` (cam != NULL: B must be width*height, ray r = pixel
+ * (r % width, r / width), out [H,W,3]) or from explicit arrays origins/dirs/viewdirs [B,3] in world
+ * space with unit dirs (cam == NULL).  out_rgb [B,3]. */
+int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, float* out_rgb,
+                          void* stream);
+/* Gradient of sum(out_rgb * grad_out) w.r.t. tree->data, ACCUMULATED (atomic adds) into grad_data
+ * [n_internal,2,2,2,D] -- zero it first (optimizer.zero_grad(), octree/optimization.py:221-224).
+ * Training semantics: exact marching (stop_thresh is ignored: no early-stop rescale). */
+int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* grad_out,
+                          float* grad_data, void* stream);
+
+/* mse = mean((clamp(im,0,1) - gt)^2) and its gradient w.r.t. im  (octree/optimization.py:217-219);
+ * n = number of floats.  sse_out: device scalar receiving sum of squares (mse = sse/n); grad may be NULL. */
+int pxo_image_mse(const float* im, const float* gt, int64_t n, float* grad, float* sse_out, void* stream);
+
+/* torch.optim.SGD step on the tree data (octree/optimization.py:176-181): with momentum mu > 0,
+ * buf = mu*buf + g (buf = g on the first step), g' = g + mu*buf if nesterov else buf; p -= lr * g'. */
+int pxo_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float mu,
+                 int nesterov, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLENOCTREE_OCTREE_H_ */

@@ -1,4 +1,4 @@
-"""ctypes binding of libplenoctree_hip.so (include/plenoctree_hip.h).
+"""ctypes binding of libplenoctree_hip.so (include/plenoctree_hip.h, include/plenoctree_octree.h).
 
 The library is the product path: there is no CPU fallback.  Loading fails loudly if the
 shared object is missing, and every call raises PxoError on a non-zero status.
@@ -51,10 +51,27 @@ class PxoLeaf(Structure):
     ]
 
 
+class PxoRenderOpts(Structure):
+    _fields_ = [("step_size", c_float), ("background_brightness", c_float), ("sigma_thresh", c_float),
+                ("stop_thresh", c_float)]
+
+
+class PxoTree(Structure):
+    _fields_ = [("child", c_void_p), ("data", c_void_p), ("n_internal", c_int64), ("data_dim", c_int32),
+                ("basis_dim", c_int32), ("offset", c_float * 3), ("invradius", c_float * 3)]
+
+
+class PxoCamera(Structure):
+    _fields_ = [("c2w", c_void_p), ("fx", c_float), ("fy", c_float), ("width", c_int32), ("height", c_int32)]
+
+
+TREE_MAX_DEPTH = 10
+
 P = c_void_p
 CFG = POINTER(PxoCfg)
+F3 = POINTER(c_float)
 
-# name -> (restype, argtypes); must list every symbol include/plenoctree_hip.h declares
+# name -> (restype, argtypes); must list every symbol the headers under include/ declare
 SIGNATURES = {
     "pxo_last_error": (c_char_p, []),
     "pxo_version": (c_int, []),
@@ -88,6 +105,21 @@ SIGNATURES = {
     "pxo_profile_enable": (c_int, [c_int]),
     "pxo_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "pxo_grid_sigma": (c_int, [CFG, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P]),
+    # include/plenoctree_octree.h
+    "pxo_threshold_mask": (c_int, [P, c_int64, c_float, P, P]),
+    "pxo_tree_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
+    "pxo_tree_count_nodes": (c_int, [P, c_int, P, c_size_t, POINTER(c_int64), P]),
+    "pxo_tree_build": (c_int, [P, c_size_t, c_int, POINTER(c_int64), P, P, P]),
+    "pxo_tree_sample_cells": (c_int, [P, c_int64, c_int64, c_int, P, F3, F3, P, P]),
+    "pxo_tree_relu_sigma": (c_int, [P, c_int64, c_int, P]),
+    "pxo_grid_weight_render": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
+                                       F3, F3, P, P]),
+    "pxo_octree_render_fwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
+                                      POINTER(PxoRenderOpts), P, P]),
+    "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
+                                      POINTER(PxoRenderOpts), P, P, P]),
+    "pxo_image_mse": (c_int, [P, P, c_int64, P, P, P]),
+    "pxo_sgd_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_int, P]),
 }
 
 _lib = None

@@ -6,7 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplenoctree_hip.so")
-SOURCES = ["pxo_api.hip", "mlp_kernels.hip", "wgrad_kernels.hip", "render_kernels.hip", "optim_kernels.hip"]
+SOURCES = ["pxo_api.hip", "mlp_kernels.hip", "wgrad_kernels.hip", "render_kernels.hip", "optim_kernels.hip",
+           "octree_kernels.hip"]
+# per-source flags: the octree marchers are compiled without fused contraction (see the file header)
+SOURCE_FLAGS = {"octree_kernels.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -16,6 +19,7 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(HERE, "..", "include", "plenoctree_hip.h"))
+    deps.append(os.path.join(HERE, "..", "include", "plenoctree_octree.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -42,7 +46,7 @@ def _build(force, verbose, extra_flags, objdir):
     for src in SOURCES:
         obj = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *SOURCE_FLAGS.get(src, []), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

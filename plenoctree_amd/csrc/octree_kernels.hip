@@ -1,0 +1,843 @@
+// PlenOctree side of the path on gfx950: N3Tree build from the grid mask, leaf sampling, the
+// training-view weight mask over the dense grid, and the octree volume renderer (forward + gradient).
+// C ABI: include/plenoctree_octree.h (reference call sites cited there).
+//
+// This translation unit is compiled with -ffp-contract=off: the marching arithmetic (sample positions,
+// cell exits, step lengths) is written one rounding per operation, so that the sequence of cells a ray
+// visits does not depend on how the compiler fuses multiply-adds (oracle/octree_oracle.py takes the
+// same steps in numpy float32).
+//
+// Tree build: with whole levels refined at a time (octree/extraction.py:341-350), svox's node order --
+// breadth-first, each level sorted by packed parent cell index -- is the Morton (z-curve) order of the
+// occupied cells of that level.  So the build is: occupancy pyramid stored in Morton order, one exclusive
+// scan per level (rank of a cell = its node index inside the level), and the 8 children of cell m are the
+// contiguous cells 8m..8m+7 of the next level.  No sort, no pointer chasing, all streams are linear.
+//
+// Renderer: one ray per 16-lane row of the wave (4 rays per wave64).  The 16 lanes walk the tree together
+// (uniform control flow inside a row), each lane owns data channels lane, lane+16, ... of the leaf, so a
+// leaf's 3*K coefficients are fetched as K/16*3 coalesced 64-byte row loads and reduced with row-local
+// DPP shuffles.  The node path of the previous sample is kept in LDS; the descent for the next sample
+// resumes at the deepest node the two positions share instead of the root.
+#include "pxo_common.h"
+#include "pxo_sh.h"
+#include "../../include/plenoctree_octree.h"
+
+namespace pxo {
+
+constexpr int kMaxD = PXO_TREE_MAX_DEPTH;
+constexpr int kBits = kMaxD + 1;             // bits per axis of the finest cell grid (2^(depth+1))
+
+// ------------------------------------------------------------------------------------------
+// Morton helpers: cell (x,y,z) of a 2^d grid <-> m, x the most significant bit of each triple
+// (cell index inside a node = (i*2+j)*2+k, svox packed order).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline void morton_decode(uint64_t m, int d, uint32_t& x, uint32_t& y, uint32_t& z) {
+  x = y = z = 0;
+  for (int b = 0; b < d; ++b) {
+    const uint32_t t = (uint32_t)(m >> (3 * b)) & 7u;
+    x |= ((t >> 2) & 1u) << b;
+    y |= ((t >> 1) & 1u) << b;
+    z |= (t & 1u) << b;
+  }
+}
+
+__host__ inline int64_t pow8(int d) { return (int64_t)1 << (3 * d); }
+
+// workspace carving (bytes): occ[1..depth], rank[1..depth], block sums, counts
+struct TreeWs {
+  int64_t occ_off[kMaxD + 1];
+  int64_t rank_off[kMaxD + 1];
+  int64_t bsum_off, count_off, total;
+};
+constexpr int kScanElems = 2048;             // elements per scan block (256 threads x 8 bytes)
+
+static TreeWs tree_ws(int depth) {
+  TreeWs w{};
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~(int64_t)255; return o; };
+  for (int d = 1; d <= depth; ++d) w.occ_off[d] = take(pow8(d));
+  for (int d = 1; d <= depth; ++d) w.rank_off[d] = take(4 * pow8(d));
+  w.bsum_off = take(4 * (pow8(depth) / kScanElems + 2));
+  w.count_off = take(8 * (kMaxD + 2));
+  w.total = off;
+  return w;
+}
+
+__global__ void threshold_mask_kernel(const float* __restrict__ v, int64_t n, float thresh, uint8_t* __restrict__ mask) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) mask[i] = v[i] >= thresh ? 1 : 0;
+}
+
+// level `depth` occupancy (Morton order) from the 2^(depth+1) mask (x slowest)
+__global__ void pyramid_base_kernel(const uint8_t* __restrict__ mask, int depth, uint8_t* __restrict__ occ) {
+  const int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (m >= ((int64_t)1 << (3 * depth))) return;
+  uint32_t x, y, z;
+  morton_decode((uint64_t)m, depth, x, y, z);
+  const int64_t reso = (int64_t)2 << depth;
+  uint32_t any = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t base = ((int64_t)(2 * x + (c >> 1)) * reso + (2 * y + (c & 1))) * reso + 2 * z;
+    any |= *reinterpret_cast<const uint16_t*>(mask + base);   // 2z is even, reso even: 2-byte aligned
+  }
+  occ[m] = any ? 1 : 0;
+}
+
+__global__ void pyramid_up_kernel(const uint8_t* __restrict__ fine, int64_t n_coarse, uint8_t* __restrict__ coarse) {
+  const int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (m >= n_coarse) return;
+  coarse[m] = reinterpret_cast<const uint64_t*>(fine)[m] ? 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t bytes_sum(uint64_t v) {       // bytes are 0/1
+  return (uint32_t)__popcll(v);
+}
+
+// block-level exclusive scan of 256 per-thread counts
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t& block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) base += s_wave[w];
+    tot += s_wave[w];
+  }
+  block_total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_blocksum_kernel(const uint8_t* __restrict__ occ, int64_t n,
+                                                             uint32_t* __restrict__ bsum) {
+  __shared__ uint32_t s_wave[4];
+  const int64_t i8 = (blockIdx.x * (int64_t)256 + threadIdx.x) * 8;
+  const uint32_t v = i8 < n ? bytes_sum(*reinterpret_cast<const uint64_t*>(occ + i8)) : 0;
+  uint32_t tot;
+  block_excl_scan(v, s_wave, tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single block: in-place exclusive scan of nb block sums; total -> *count
+__global__ __launch_bounds__(256) void scan_sums_kernel(uint32_t* __restrict__ bsum, int64_t nb, int64_t* __restrict__ count) {
+  __shared__ uint32_t s_wave[4];
+  uint32_t carry = 0;
+  for (int64_t base = 0; base < nb; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? bsum[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, s_wave, tot);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_final_kernel(const uint8_t* __restrict__ occ, int64_t n,
+                                                          const uint32_t* __restrict__ bsum, int32_t* __restrict__ rank) {
+  __shared__ uint32_t s_wave[4];
+  const int64_t i8 = (blockIdx.x * (int64_t)256 + threadIdx.x) * 8;
+  const uint64_t bytes = i8 < n ? *reinterpret_cast<const uint64_t*>(occ + i8) : 0;
+  uint32_t tot;
+  uint32_t run = bsum[blockIdx.x] + block_excl_scan(bytes_sum(bytes), s_wave, tot);
+  if (i8 >= n) return;
+  int32_t r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    r[k] = (int32_t)run;
+    run += (uint32_t)(bytes >> (8 * k)) & 1u;
+  }
+  reinterpret_cast<int4*>(rank + i8)[0] = make_int4(r[0], r[1], r[2], r[3]);
+  reinterpret_cast<int4*>(rank + i8)[1] = make_int4(r[4], r[5], r[6], r[7]);
+}
+
+// nodes of depth d (cells m of level d that are occupied; d = 0: the root)
+struct LevelPtrs {
+  const uint8_t* occ[kMaxD + 2];
+  const int32_t* rank[kMaxD + 2];
+  int64_t start[kMaxD + 2];
+};
+
+__global__ void tree_emit_kernel(LevelPtrs lv, int d, int depth, int32_t* __restrict__ child,
+                                 int32_t* __restrict__ parent_depth) {
+  const int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (m >= ((int64_t)1 << (3 * d))) return;
+  if (d > 0 && !lv.occ[d][m]) return;
+  const int64_t n = d == 0 ? 0 : lv.start[d] + lv.rank[d][m];
+  int32_t ch[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    ch[c] = 0;
+    if (d < depth) {
+      const int64_t mc = m * 8 + c;
+      if (lv.occ[d + 1][mc]) ch[c] = (int32_t)(lv.start[d + 1] + lv.rank[d + 1][mc] - n);
+    }
+  }
+  reinterpret_cast<int4*>(child + n * 8)[0] = make_int4(ch[0], ch[1], ch[2], ch[3]);
+  reinterpret_cast<int4*>(child + n * 8)[1] = make_int4(ch[4], ch[5], ch[6], ch[7]);
+  int64_t packed = 0;
+  if (d > 0) {
+    const int64_t pm = m >> 3;
+    const int64_t pn = d == 1 ? 0 : lv.start[d - 1] + lv.rank[d - 1][pm];
+    packed = pn * 8 + (m & 7);
+  }
+  parent_depth[n * 2] = (int32_t)packed;
+  parent_depth[n * 2 + 1] = d;
+}
+
+// ------------------------------------------------------------------------------------------
+// leaf samples
+// ------------------------------------------------------------------------------------------
+__global__ void tree_sample_cells_kernel(const int32_t* __restrict__ parent_depth, int64_t node0, int64_t n_nodes,
+                                         int S, const float* __restrict__ u, float ox, float oy, float oz,
+                                         float ix, float iy, float iz, float* __restrict__ pts) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;      // (node, cell, sample)
+  if (q >= n_nodes * 8 * S) return;
+  const int64_t cellq = q / S;
+  int64_t node = node0 + (cellq >> 3);
+  const int cell = (int)(cellq & 7);
+  const int depth = parent_depth[node * 2 + 1];
+  uint32_t X = (cell >> 2) & 1, Y = (cell >> 1) & 1, Z = cell & 1;
+  for (int lvl = 1; lvl <= depth; ++lvl) {
+    const int32_t packed = parent_depth[node * 2];
+    const int c = packed & 7;
+    X |= (uint32_t)((c >> 2) & 1) << lvl;
+    Y |= (uint32_t)((c >> 1) & 1) << lvl;
+    Z |= (uint32_t)(c & 1) << lvl;
+    node = packed >> 3;
+  }
+  const float side = 1.0f / (float)((uint32_t)2 << depth);
+  const float px = (float)X * side + u[q * 3] * side;
+  const float py = (float)Y * side + u[q * 3 + 1] * side;
+  const float pz = (float)Z * side + u[q * 3 + 2] * side;
+  pts[q * 3] = (px - ox) / ix;
+  pts[q * 3 + 1] = (py - oy) / iy;
+  pts[q * 3 + 2] = (pz - oz) / iz;
+}
+
+__global__ void tree_relu_sigma_kernel(float* __restrict__ data, int64_t n_cells, int dim) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n_cells) {
+    float& s = data[i * dim + dim - 1];
+    s = fmaxf(s, 0.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ray set-up shared by the marchers (svox cam2world_ray / transform_coord / _get_delta_scale / _dda_unit)
+// ------------------------------------------------------------------------------------------
+struct TreeRay {
+  float o[3], d[3], invdir[3], vdir[3];
+  float delta_scale, tmin, tmax;
+};
+
+__device__ __forceinline__ void dda_unit(const float (&cen)[3], const float (&invdir)[3], float& tmin, float& tmax) {
+  tmin = 0.0f;
+  tmax = 1e9f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float t1 = -cen[a] * invdir[a];
+    const float t2 = t1 + invdir[a];
+    tmin = fmaxf(tmin, fminf(t1, t2));
+    tmax = fminf(tmax, fmaxf(t1, t2));
+  }
+}
+
+__device__ __forceinline__ void camera_ray(const float* __restrict__ c2w, float fx, float fy, int W, int H, int px, int py,
+                                           float (&origin)[3], float (&dir)[3]) {
+  float x = ((float)px - 0.5f * (float)W) / fx;
+  float y = -((float)py - 0.5f * (float)H) / fy;
+  float z = sqrtf((x * x + y * y) + 1.0f);
+  x = x / z;
+  y = y / z;
+  z = -1.0f / z;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    dir[a] = (c2w[a * 4] * x + c2w[a * 4 + 1] * y) + c2w[a * 4 + 2] * z;
+    origin[a] = c2w[a * 4 + 3];
+  }
+}
+
+__device__ __forceinline__ void to_tree_ray(const float (&origin)[3], const float (&dir)[3], const float* offset,
+                                            const float* invradius, TreeRay& r) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    r.o[a] = offset[a] + invradius[a] * origin[a];
+    r.d[a] = dir[a] * invradius[a];
+  }
+  const float nrm = sqrtf((r.d[0] * r.d[0] + r.d[1] * r.d[1]) + r.d[2] * r.d[2]);
+  r.delta_scale = 1.0f / nrm;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    r.d[a] = r.d[a] * r.delta_scale;
+    r.invdir[a] = 1.0f / (r.d[a] + 1e-9f);
+  }
+  dda_unit(r.o, r.invdir, r.tmin, r.tmax);
+}
+
+__device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.0f), 1.0f - 1e-6f); }
+
+// ------------------------------------------------------------------------------------------
+// grid weight render: one thread per (camera, pixel)
+// ------------------------------------------------------------------------------------------
+struct Vec3 { float v[3]; };
+
+__global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restrict__ sigma, int reso,
+                                                           const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
+                                                           int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
+                                                           int* __restrict__ weight_bits) {
+  // 8x8 pixel tiles per 64-thread wave keep the rays of a wave in neighbouring voxels
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const int64_t b = blockIdx.x;
+  const int cam = (int)(b / ((int64_t)tiles_x * tiles_y));
+  const int tile = (int)(b % ((int64_t)tiles_x * tiles_y));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int px = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
+  const int py = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (cam >= n_cams || px >= W || py >= H) return;
+  float origin[3], dir[3];
+  camera_ray(c2w_all + (int64_t)cam * 12, fx, fy, W, H, px, py, origin, dir);
+  TreeRay r;
+  to_tree_ray(origin, dir, offset.v, invradius.v, r);
+  if (r.tmax < 0.0f || r.tmin > r.tmax) return;
+  const float cube = (float)reso;
+  float t = r.tmin, light = 1.0f;
+  while (t < r.tmax) {
+    float local[3];
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float p = clamp_coord(r.o[a] + t * r.d[a]) * cube;
+      const float fl = floorf(p);
+      c[a] = (int)fl;
+      local[a] = p - fl;
+    }
+    float s0, s1;
+    dda_unit(local, r.invdir, s0, s1);
+    const float delta_t = (s1 - s0) / cube + opt.step_size;
+    const int64_t idx = ((int64_t)c[0] * reso + c[1]) * reso + c[2];
+    const float sg = sigma[idx];
+    if (sg > opt.sigma_thresh) {
+      const float att = expf(-(delta_t * r.delta_scale) * sg);
+      const float w = light * (1.0f - att);
+      light = light * att;
+      const int wb = __float_as_int(w);
+      if (wb > weight_bits[idx]) atomicMax(weight_bits + idx, wb);     // w >= 0: integer order == float order
+      if (light <= opt.stop_thresh) return;
+    }
+    const float tn = t + delta_t;
+    if (!(tn > t)) return;                     // step below the resolution of t: stop rather than spin
+    t = tn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// octree renderer
+// ------------------------------------------------------------------------------------------
+constexpr int kRow = 16;                       // lanes per ray
+constexpr int kRenderThreads = 256;
+constexpr int kRaysPerBlock = kRenderThreads / kRow;
+constexpr int kMaxLoads = 5;                   // ceil(75 / 16)
+
+__device__ __forceinline__ float row_sum(float v) {   // sum over the 16 lanes of a row, result in every lane
+  v += __shfl_xor(v, 1, kRow);
+  v += __shfl_xor(v, 2, kRow);
+  v += __shfl_xor(v, 4, kRow);
+  v += __shfl_xor(v, 8, kRow);
+  return v;
+}
+
+// first `basis_dim` SH basis values (the bands of a lower degree are a prefix of the degree-4 list)
+__device__ __forceinline__ void sh_basis_dyn(int basis_dim, float x, float y, float z, float* Y) {
+  float tmp[25];
+  sh_basis<4>(x, y, z, tmp);
+#pragma unroll
+  for (int i = 0; i < 25; ++i)
+    if (i < basis_dim) Y[i] = tmp[i];
+}
+
+struct RenderArgs {
+  PxoTree tree;
+  PxoCamera cam;
+  int has_cam;
+  const float* origins;
+  const float* dirs;
+  const float* viewdirs;
+  int64_t B;
+  PxoRenderOpts opt;
+};
+
+// Per-row marching state + the leaf lookup with path reuse.
+struct Marcher {
+  uint32_t pX, pY, pZ;
+  int last_depth;
+  bool first;
+  int* stack;                                  // LDS, kMaxD + 2 entries of this row
+
+  __device__ __forceinline__ void init(int* s) {
+    stack = s;
+    first = true;
+    last_depth = 0;
+    pX = pY = pZ = 0;
+    s[0] = 0;
+  }
+  // finds the leaf containing pos (tree coords, clamped); returns flat cell index node*8+cell
+  __device__ __forceinline__ int64_t find(const int32_t* __restrict__ child, const float (&pos)[3], int& depth_out) {
+    const uint32_t X = (uint32_t)(pos[0] * (float)(1u << kBits));
+    const uint32_t Y = (uint32_t)(pos[1] * (float)(1u << kBits));
+    const uint32_t Z = (uint32_t)(pos[2] * (float)(1u << kBits));
+    int depth = 0;
+    if (!first) {
+      const uint32_t diff = (X ^ pX) | (Y ^ pY) | (Z ^ pZ);
+      const int common = diff ? (__clz((int)diff) - (32 - kBits)) : kBits;     // leading bit-levels shared
+      depth = min(common, last_depth);
+    }
+    first = false;
+    pX = X; pY = Y; pZ = Z;
+    int node = stack[depth];
+    int cell;
+    while (true) {
+      const int bit = kBits - 1 - depth;
+      cell = (int)(((X >> bit) & 1u) << 2 | ((Y >> bit) & 1u) << 1 | ((Z >> bit) & 1u));
+      const int skip = child[(int64_t)node * 8 + cell];
+      if (skip == 0) break;
+      node += skip;
+      ++depth;
+      stack[depth] = node;
+    }
+    last_depth = depth;
+    depth_out = depth;
+    return (int64_t)node * 8 + cell;
+  }
+};
+
+// MODE 0: forward (writes out_rgb).  MODE 1: gradient w.r.t. tree data (two marches per ray).
+template <int MODE>
+__global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArgs A, float* __restrict__ out_rgb,
+                                                                        const float* __restrict__ grad_out,
+                                                                        float* __restrict__ grad_data) {
+  __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
+  __shared__ float s_basis[kRaysPerBlock][25];
+  const int row = threadIdx.x / kRow, l = threadIdx.x % kRow;
+  int64_t ray;
+  float origin[3], dir[3], vdir[3];
+  bool active = true;
+  if (A.has_cam) {
+    // 4x4 pixel tile per block, 2x2 per wave
+    const int W = A.cam.width, H = A.cam.height;
+    const int tiles_x = (W + 3) / 4;
+    const int bx = (int)(blockIdx.x % tiles_x), by = (int)(blockIdx.x / tiles_x);
+    const int wv = row >> 2, q = row & 3;
+    const int px = bx * 4 + (wv & 1) * 2 + (q & 1), py = by * 4 + (wv >> 1) * 2 + (q >> 1);
+    active = px < W && py < H;
+    ray = (int64_t)py * W + px;
+    if (active) {
+      camera_ray(A.cam.c2w, A.cam.fx, A.cam.fy, W, H, px, py, origin, dir);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) vdir[a] = dir[a];
+    }
+  } else {
+    ray = blockIdx.x * (int64_t)kRaysPerBlock + row;
+    active = ray < A.B;
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        origin[a] = A.origins[ray * 3 + a];
+        dir[a] = A.dirs[ray * 3 + a];
+        vdir[a] = A.viewdirs[ray * 3 + a];
+      }
+    }
+  }
+  if (!active) return;                         // whole rows leave together; no block-level barrier below
+
+  const int K = A.tree.basis_dim, D = A.tree.data_dim;
+  const float bg = A.opt.background_brightness;
+  TreeRay r;
+  to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
+  const bool miss = r.tmax < 0.0f || r.tmin > r.tmax;
+  if (MODE == 0 && miss) {
+    if (l < 3) out_rgb[ray * 3 + l] = bg;
+    return;
+  }
+  if (MODE == 1 && miss) return;
+
+  // per-lane channel ownership: data index l + 16 j -> (channel, SH component)
+  if (l == 0) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
+  __builtin_amdgcn_wave_barrier();
+  const int nload = (D - 1 + kRow - 1) / kRow;
+  float b0[kMaxLoads], b1[kMaxLoads], b2[kMaxLoads];
+#pragma unroll
+  for (int j = 0; j < kMaxLoads; ++j) {
+    const int idx = l + kRow * j;
+    float bas = 0.0f;
+    int ch = -1;
+    if (j < nload && idx < D - 1) {
+      ch = idx / K;
+      bas = s_basis[row][idx - ch * K];
+    }
+    b0[j] = ch == 0 ? bas : 0.0f;
+    b1[j] = ch == 1 ? bas : 0.0f;
+    b2[j] = ch == 2 ? bas : 0.0f;
+  }
+  const float* __restrict__ data = A.tree.data;
+  const int32_t* __restrict__ child = A.tree.child;
+
+  float g[3] = {0.f, 0.f, 0.f};
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = grad_out[ray * 3 + c];
+  }
+  float accum = 0.0f;                          // MODE 1: sum_c g_c * out_c, then the part behind the sample
+
+  // pass 0 composites; in MODE 1 pass 1 re-marches and scatters the gradient
+  for (int pass = 0; pass <= MODE; ++pass) {
+    Marcher mk;
+    mk.init(s_stack[row]);
+    float t = r.tmin, light = 1.0f;
+    float out[3] = {0.f, 0.f, 0.f};
+    bool stopped = false;
+    while (t < r.tmax) {
+      float pos[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + t * r.d[a]);
+      int depth;
+      const int64_t leaf = mk.find(child, pos, depth);
+      const float cube = (float)(2u << depth);
+      float local[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float p = pos[a] * cube;
+        local[a] = p - floorf(p);
+      }
+      float s0, s1;
+      dda_unit(local, r.invdir, s0, s1);
+      const float delta_t = (s1 - s0) / cube + A.opt.step_size;
+      const float* __restrict__ val = data + leaf * D;
+      const float sg = val[D - 1];
+      if (sg > A.opt.sigma_thresh) {
+        const float dtw = delta_t * r.delta_scale;
+        const float att = expf(-dtw * sg);
+        const float weight = light * (1.0f - att);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxLoads; ++j) {
+          if (j < nload) {
+            const int idx = l + kRow * j;
+            const float v = idx < D - 1 ? val[idx] : 0.0f;
+            p0 += v * b0[j];
+            p1 += v * b1[j];
+            p2 += v * b2[j];
+          }
+        }
+        p0 = row_sum(p0);
+        p1 = row_sum(p1);
+        p2 = row_sum(p2);
+        const float c0 = 1.0f / (1.0f + expf(-p0)), c1 = 1.0f / (1.0f + expf(-p1)), c2 = 1.0f / (1.0f + expf(-p2));
+        if (pass == 0) {
+          out[0] += weight * c0;
+          out[1] += weight * c1;
+          out[2] += weight * c2;
+          light = light * att;
+          if (MODE == 0 && light <= A.opt.stop_thresh) {
+            const float scale = 1.0f / (1.0f - light);
+            out[0] *= scale; out[1] *= scale; out[2] *= scale;
+            stopped = true;
+            break;
+          }
+        } else {
+          const float total = (g[0] * c0 + g[1] * c1) + g[2] * c2;
+          const float d0 = weight * g[0] * c0 * (1.0f - c0);
+          const float d1 = weight * g[1] * c1 * (1.0f - c1);
+          const float d2 = weight * g[2] * c2 * (1.0f - c2);
+          float* __restrict__ gv = grad_data + leaf * D;
+#pragma unroll
+          for (int j = 0; j < kMaxLoads; ++j) {
+            if (j < nload) {
+              const int idx = l + kRow * j;
+              if (idx < D - 1) unsafeAtomicAdd(gv + idx, (b0[j] * d0 + b1[j] * d1) + b2[j] * d2);
+            }
+          }
+          light = light * att;
+          accum -= weight * total;
+          if (l == 0) unsafeAtomicAdd(gv + D - 1, dtw * (total * light - accum));
+        }
+      }
+      const float tn = t + delta_t;
+      if (!(tn > t)) break;                    // step below the resolution of t: stop rather than spin
+      t = tn;
+    }
+    if (pass == 0) {
+      if (MODE == 0) {
+        if (!stopped) {
+          out[0] += light * bg; out[1] += light * bg; out[2] += light * bg;
+        }
+        if (l < 3) out_rgb[ray * 3 + l] = l == 0 ? out[0] : (l == 1 ? out[1] : out[2]);
+      } else {
+        accum = (g[0] * (out[0] + light * bg) + g[1] * (out[1] + light * bg)) + g[2] * (out[2] + light * bg);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// image loss and SGD
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_mse_kernel(const float* __restrict__ im, const float* __restrict__ gt, int64_t n,
+                                                         float* __restrict__ grad, float* __restrict__ sse) {
+  __shared__ float s_part[4];
+  float acc = 0.0f;
+  const float scale = 2.0f / (float)n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = im[i];
+    const float c = fminf(fmaxf(v, 0.0f), 1.0f);
+    const float e = c - gt[i];
+    acc += e * e;
+    if (grad) grad[i] = (v >= 0.0f && v <= 1.0f) ? scale * e : 0.0f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sse, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n, float lr,
+                           float mu, int nesterov, int first) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (mu != 0.0f) {
+    const float b = first ? gi : mu * buf[i] + gi;
+    buf[i] = b;
+    gi = nesterov ? gi + mu * b : b;
+  }
+  p[i] = p[i] - lr * gi;
+}
+
+}  // namespace pxo
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace pxo;
+
+static inline int64_t blocks_for(int64_t n, int threads) { return (n + threads - 1) / threads; }
+
+extern "C" {
+
+int pxo_threshold_mask(const float* value, int64_t n, float thresh, uint8_t* mask, void* stream) {
+  PXO_REQUIRE(n >= 0, "pxo_threshold_mask: n < 0");
+  if (n == 0) return PXO_OK;
+  PXO_REQUIRE(value && mask, "pxo_threshold_mask: null pointer");
+  hipLaunchKernelGGL(threshold_mask_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, value, n,
+                     thresh, mask);
+  return check_launch("threshold_mask");
+}
+
+int pxo_tree_workspace_bytes(int depth, size_t* bytes) {
+  PXO_REQUIRE(depth >= 1 && depth <= kMaxD, "pxo_tree_workspace_bytes: depth %d outside [1,%d]", depth, kMaxD);
+  PXO_REQUIRE(bytes, "pxo_tree_workspace_bytes: null pointer");
+  *bytes = (size_t)tree_ws(depth).total;
+  return PXO_OK;
+}
+
+static int scan_level(const uint8_t* occ, int64_t n, uint32_t* bsum, int32_t* rank, int64_t* count, hipStream_t s) {
+  const int64_t nb = blocks_for(n, kScanElems);
+  hipLaunchKernelGGL(scan_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, s, occ, n, bsum);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, s, bsum, nb, count);
+  hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, s, occ, n, (const uint32_t*)bsum, rank);
+  return check_launch("tree scan");
+}
+
+int pxo_tree_count_nodes(const uint8_t* mask, int depth, void* ws, size_t ws_bytes, int64_t* level_nodes, void* stream) {
+  PXO_REQUIRE(depth >= 1 && depth <= kMaxD, "pxo_tree_count_nodes: depth %d outside [1,%d]", depth, kMaxD);
+  PXO_REQUIRE(mask && ws && level_nodes, "pxo_tree_count_nodes: null pointer");
+  const TreeWs w = tree_ws(depth);
+  if (ws_bytes < (size_t)w.total) {
+    set_error("pxo_tree_count_nodes: workspace %zu < %lld", ws_bytes, (long long)w.total);
+    return PXO_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)ws;
+  uint8_t* occ_d = (uint8_t*)(base + w.occ_off[depth]);
+  hipLaunchKernelGGL(pyramid_base_kernel, dim3((unsigned)blocks_for(pow8(depth), 256)), dim3(256), 0, s, mask, depth, occ_d);
+  for (int d = depth - 1; d >= 1; --d) {
+    hipLaunchKernelGGL(pyramid_up_kernel, dim3((unsigned)blocks_for(pow8(d), 256)), dim3(256), 0, s,
+                       (const uint8_t*)(base + w.occ_off[d + 1]), pow8(d), (uint8_t*)(base + w.occ_off[d]));
+  }
+  int64_t* counts = (int64_t*)(base + w.count_off);
+  for (int d = 1; d <= depth; ++d) {
+    const int rc = scan_level((const uint8_t*)(base + w.occ_off[d]), pow8(d), (uint32_t*)(base + w.bsum_off),
+                              (int32_t*)(base + w.rank_off[d]), counts + d, s);
+    if (rc) return rc;
+  }
+  if (hipMemcpyAsync(level_nodes + 1, counts + 1, sizeof(int64_t) * depth, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    set_error("pxo_tree_count_nodes: %s", hipGetErrorString(hipGetLastError()));
+    return PXO_ERR_HIP;
+  }
+  level_nodes[0] = 1;
+  return PXO_OK;
+}
+
+int pxo_tree_build(const void* ws, size_t ws_bytes, int depth, const int64_t* level_nodes, int32_t* child,
+                   int32_t* parent_depth, void* stream) {
+  PXO_REQUIRE(depth >= 1 && depth <= kMaxD, "pxo_tree_build: depth %d outside [1,%d]", depth, kMaxD);
+  PXO_REQUIRE(ws && level_nodes && child && parent_depth, "pxo_tree_build: null pointer");
+  const TreeWs w = tree_ws(depth);
+  if (ws_bytes < (size_t)w.total) {
+    set_error("pxo_tree_build: workspace %zu < %lld", ws_bytes, (long long)w.total);
+    return PXO_ERR_WORKSPACE;
+  }
+  LevelPtrs lv{};
+  const char* base = (const char*)ws;
+  int64_t start = 0;
+  for (int d = 0; d <= depth; ++d) {
+    lv.start[d] = start;
+    start += level_nodes[d];
+    if (d >= 1) {
+      lv.occ[d] = (const uint8_t*)(base + w.occ_off[d]);
+      lv.rank[d] = (const int32_t*)(base + w.rank_off[d]);
+    }
+  }
+  PXO_REQUIRE(start < ((int64_t)1 << 28), "pxo_tree_build: %lld nodes exceed the int32 packed-index range", (long long)start);
+  for (int d = 0; d <= depth; ++d) {
+    if (level_nodes[d] == 0) break;
+    hipLaunchKernelGGL(tree_emit_kernel, dim3((unsigned)blocks_for(pow8(d), 256)), dim3(256), 0, (hipStream_t)stream, lv, d,
+                       depth, child, parent_depth);
+  }
+  return check_launch("tree_emit");
+}
+
+int pxo_tree_sample_cells(const int32_t* parent_depth, int64_t node0, int64_t n_nodes, int S, const float* u,
+                          const float offset[3], const float invradius[3], float* points, void* stream) {
+  PXO_REQUIRE(n_nodes >= 0 && node0 >= 0 && S >= 1, "pxo_tree_sample_cells: bad sizes");
+  if (n_nodes == 0) return PXO_OK;
+  PXO_REQUIRE(parent_depth && u && offset && invradius && points, "pxo_tree_sample_cells: null pointer");
+  const int64_t n = n_nodes * 8 * S;
+  hipLaunchKernelGGL(tree_sample_cells_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     parent_depth, node0, n_nodes, S, u, offset[0], offset[1], offset[2], invradius[0], invradius[1],
+                     invradius[2], points);
+  return check_launch("tree_sample_cells");
+}
+
+int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream) {
+  PXO_REQUIRE(n_cells >= 0 && data_dim >= 1, "pxo_tree_relu_sigma: bad sizes");
+  if (n_cells == 0) return PXO_OK;
+  PXO_REQUIRE(data, "pxo_tree_relu_sigma: null pointer");
+  hipLaunchKernelGGL(tree_relu_sigma_kernel, dim3((unsigned)blocks_for(n_cells, 256)), dim3(256), 0, (hipStream_t)stream, data,
+                     n_cells, data_dim);
+  return check_launch("tree_relu_sigma");
+}
+
+static int check_opts(const PxoRenderOpts* o, const char* who) {
+  PXO_REQUIRE(o, "%s: null options", who);
+  PXO_REQUIRE(o->step_size > 0.0f, "%s: step_size must be > 0 (marching would not advance)", who);
+  return PXO_OK;
+}
+
+int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
+                           int width, int height, const PxoRenderOpts* opts, const float offset[3],
+                           const float invradius[3], float* grid_weight, void* stream) {
+  if (int rc = check_opts(opts, "pxo_grid_weight_render")) return rc;
+  PXO_REQUIRE(reso >= 1 && reso <= 2048 && n_cams >= 0 && width >= 1 && height >= 1, "pxo_grid_weight_render: bad sizes");
+  PXO_REQUIRE(fx > 0.0f && fy > 0.0f, "pxo_grid_weight_render: focal length must be > 0");
+  if (n_cams == 0) return PXO_OK;
+  PXO_REQUIRE(sigma_grid && c2w_all && offset && invradius && grid_weight, "pxo_grid_weight_render: null pointer");
+  Vec3 o{{offset[0], offset[1], offset[2]}}, ir{{invradius[0], invradius[1], invradius[2]}};
+  const int64_t tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
+  PXO_REQUIRE(tiles * n_cams < ((int64_t)1 << 31), "pxo_grid_weight_render: too many tiles for one launch");
+  hipLaunchKernelGGL(grid_weight_kernel, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, (hipStream_t)stream, sigma_grid, reso,
+                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(grid_weight));
+  return check_launch("grid_weight_render");
+}
+
+static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
+                       const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const char* who, RenderArgs& A,
+                       unsigned& grid) {
+  if (int rc = check_opts(opts, who)) return rc;
+  PXO_REQUIRE(tree && tree->child && tree->data, "%s: null tree", who);
+  const int K = tree->basis_dim;
+  PXO_REQUIRE(K == 1 || K == 4 || K == 9 || K == 16 || K == 25, "%s: basis_dim %d is not an SH format (1,4,9,16,25)", who, K);
+  PXO_REQUIRE(tree->data_dim == 3 * K + 1, "%s: data_dim %d != 3*basis_dim+1", who, tree->data_dim);
+  PXO_REQUIRE(tree->n_internal >= 1 && tree->n_internal < ((int64_t)1 << 28), "%s: n_internal out of range", who);
+  PXO_REQUIRE(B >= 0, "%s: B < 0", who);
+  A.tree = *tree;
+  A.opt = *opts;
+  A.B = B;
+  A.has_cam = cam != nullptr;
+  int64_t blocks;
+  if (cam) {
+    PXO_REQUIRE(cam->c2w && cam->width >= 1 && cam->height >= 1 && cam->fx > 0.0f && cam->fy > 0.0f, "%s: bad camera", who);
+    PXO_REQUIRE(B == (int64_t)cam->width * cam->height, "%s: B must be width*height in camera mode", who);
+    A.cam = *cam;
+    A.origins = A.dirs = A.viewdirs = nullptr;
+    blocks = (int64_t)((cam->width + 3) / 4) * ((cam->height + 3) / 4);
+  } else {
+    PXO_REQUIRE(B == 0 || (origins && dirs && viewdirs), "%s: null ray arrays", who);
+    A.cam = PxoCamera{};
+    A.origins = origins; A.dirs = dirs; A.viewdirs = viewdirs;
+    blocks = blocks_for(B, kRaysPerBlock);
+  }
+  PXO_REQUIRE(blocks < ((int64_t)1 << 31), "%s: too many rays for one launch", who);
+  grid = (unsigned)blocks;
+  return PXO_OK;
+}
+
+int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, float* out_rgb, void* stream) {
+  RenderArgs A;
+  unsigned grid;
+  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_fwd", A, grid)) return rc;
+  if (B == 0) return PXO_OK;
+  PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
+  hipLaunchKernelGGL(octree_render_kernel<0>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb,
+                     (const float*)nullptr, (float*)nullptr);
+  return check_launch("octree_render_fwd");
+}
+
+int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* grad_out,
+                          float* grad_data, void* stream) {
+  RenderArgs A;
+  unsigned grid;
+  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", A, grid)) return rc;
+  if (B == 0) return PXO_OK;
+  PXO_REQUIRE(grad_out && grad_data, "pxo_octree_render_bwd: null pointer");
+  hipLaunchKernelGGL(octree_render_kernel<1>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr,
+                     grad_out, grad_data);
+  return check_launch("octree_render_bwd");
+}
+
+int pxo_image_mse(const float* im, const float* gt, int64_t n, float* grad, float* sse_out, void* stream) {
+  PXO_REQUIRE(n >= 1, "pxo_image_mse: n < 1");
+  PXO_REQUIRE(im && gt && sse_out, "pxo_image_mse: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sse_out, 0, sizeof(float), s) != hipSuccess) {
+    set_error("pxo_image_mse: hipMemsetAsync failed");
+    return PXO_ERR_HIP;
+  }
+  const int64_t blocks = blocks_for(n, 256 * 8);
+  hipLaunchKernelGGL(image_mse_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, im, gt, n, grad, sse_out);
+  return check_launch("image_mse");
+}
+
+int pxo_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float mu, int nesterov,
+                 int first_step, void* stream) {
+  PXO_REQUIRE(n >= 0, "pxo_sgd_step: n < 0");
+  if (n == 0) return PXO_OK;
+  PXO_REQUIRE(params && grads, "pxo_sgd_step: null pointer");
+  PXO_REQUIRE(mu == 0.0f || momentum_buf, "pxo_sgd_step: momentum needs a buffer");
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     momentum_buf, n, lr, mu, nesterov, first_step);
+  return check_launch("sgd_step");
+}
+
+}  // extern "C"

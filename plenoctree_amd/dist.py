@@ -21,6 +21,12 @@ class Comm:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
         return t
 
+    def all_reduce_max(self, t):
+        """In-place maximum over ranks (per-voxel weight mask accumulated over camera shards)."""
+        if self.is_dist:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return t
+
     def all_gather_cat(self, t):
         """Concatenate equally-shaped per-rank tensors along dim 0, in rank order."""
         if not self.is_dist:

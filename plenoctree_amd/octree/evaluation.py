@@ -1,0 +1,53 @@
+"""Octree evaluation on the MI355X path (reference: octree/evaluation.py): loads a tree npz and reports the
+mean PSNR of its renders of the test split; test images are sharded over the GPUs.
+
+    python -m plenoctree_amd.octree.evaluation --input tree_opt.npz --config blender --data_dir ... [--write_images DIR]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .. import dist
+from ..nerf_sh.nerf import datasets, utils
+from . import extraction
+from .svox import N3Tree
+
+
+def define_flags():
+    p = utils.define_flags()
+    a = p.add_argument
+    a("--input", type=str, default="./tree_opt.npz")            # octree/evaluation.py:54-58
+    a("--write_images", type=str, default=None)                  # :64-68
+    a("--renderer_step_size", type=float, default=1e-4)          # octree/nerf/utils.py:211-215
+    a("--no_early_stop", action="store_true")
+    return p
+
+
+def main(argv=None):
+    args = define_flags().parse_args(argv)
+    utils.update_flags(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("octree.evaluation needs a ROCm GPU; the HIP path has no CPU fallback")
+    comm = dist.init_from_env()
+    torch.cuda.set_device(comm.local_rank)
+    device = torch.device("cuda", comm.local_rank)
+    dataset = datasets.get_dataset("test", args, device)
+    if comm.rank == 0:
+        print("N3Tree load", args.input, flush=True)
+    tree = N3Tree.load(args.input, map_location=device)
+    psnr, frames = extraction.eval_octree(tree, dataset, args, comm, want_frames=args.write_images is not None)
+    if comm.rank == 0:
+        print("Average PSNR", psnr, flush=True)
+    if args.write_images is not None:
+        from PIL import Image
+        os.makedirs(args.write_images, exist_ok=True)
+        for idx, im in frames:
+            Image.fromarray((im.numpy() * 255).astype(np.uint8)).save(os.path.join(args.write_images, f"{idx:03d}.png"))
+    comm.shutdown()
+    return psnr
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

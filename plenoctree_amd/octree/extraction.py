@@ -1,14 +1,18 @@
-"""Dense-grid evaluation stage of NeRF-SH -> PlenOctree extraction on the MI355X path.
+"""NeRF-SH -> PlenOctree extraction on the MI355X path (reference: octree/extraction.py).
 
-Covers the MLP loops of the reference's octree/extraction.py: `auto_scale` (:244-286), step 1's
-grid sigma evaluation (:288-320) and step 2's per-leaf sample evaluation + mean (:355-394).  The
-octree itself (svox N3Tree build/refine/sample/assign, grid_weight_render, npz format) is svox code
-outside this tree and is not reimplemented here: `main` stops at the sigma grid /
-sigma mask, which is exactly what the tree-building stage consumes.
+  step 0  auto_scale (:244-286)            sigma on a 2^depth grid -> bounding box
+  step 1  grid eval (:288-320)             sigma of MLP_1 on the 2^(depth+1) grid, x-slabs sharded over the GPUs
+          masking (:322-335)               "sigma": sigma >= thresh; "weight": max compositing weight over the
+                                           training views (calculate_grid_weights :181-214), cameras sharded
+          tree build (:337-352)            N3Tree.refine_from_mask (Morton pyramid + scans)
+  step 2  3-D antialiasing (:355-394)      S samples per deepest-level cell -> MLP_1 -> mean -> tree data,
+                                           nodes sharded over the GPUs
+  finish  relu on sigma, save npz, evaluate (:503-516)
 
-    python -m plenoctree_amd.octree.extraction --train_dir D --config blender --output grid.npz
+    python -m plenoctree_amd.octree.extraction --train_dir D --config blender --data_dir ... --output tree.npz
     python -m torch.distributed.run --nproc-per-node 8 -m plenoctree_amd.octree.extraction ...
 """
+import os
 import sys
 import time
 
@@ -16,7 +20,9 @@ import numpy as np
 import torch
 
 from .. import dist, ops
-from ..nerf_sh.nerf import models, utils
+from .. import octree_ops as oops
+from ..nerf_sh.nerf import datasets, models, utils
+from .svox import N3Tree, VolumeRenderer
 
 
 def tree_transform(center, radius):
@@ -77,50 +83,169 @@ def eval_leaf_samples(model, state, points, samples_per_cell):
     return ops.mean_over_samples(model.cfg, rgb, sigma, samples_per_cell)
 
 
-def main(argv=None):
+def calculate_grid_weights(dataset, sigmas, reso, invradius, offset, step_size, comm=None):
+    """calculate_grid_weights (:181-214): per-voxel maximum over the training cameras, camera-sharded."""
+    comm = comm or dist.Comm()
+    opts = oops.render_opts(step_size=step_size, sigma_thresh=0.0, stop_thresh=0.0)
+    cams = torch.from_numpy(np.ascontiguousarray(dataset.camtoworlds[comm.rank::comm.world, :3, :4])).to(sigmas.device)
+    weight = torch.zeros(reso ** 3, dtype=torch.float32, device=sigmas.device)
+    if cams.shape[0]:
+        oops.grid_weight_render(sigmas, reso, cams, dataset.focal, dataset.focal, dataset.w, dataset.h, opts, offset,
+                                invradius, grid_weight=weight)
+    return comm.all_reduce_max(weight)
+
+
+def step1(args, tree, model, state, dataset, comm):
+    """Grid evaluation, masking and tree build (:288-352)."""
+    reso = 2 ** (args.init_grid_depth + 1)
+    center, radius = tree_center_radius(tree)
+    sig = grid_sigma(model, state, reso, center, radius, comm)
+    approx_delta = 2.0 / reso
+    if args.masking_mode == "sigma":
+        mask = oops.threshold_mask(sig, -np.log(1.0 - args.alpha_thresh) / approx_delta)
+    elif args.masking_mode == "weight":
+        weights = calculate_grid_weights(dataset, sig, reso, tree.invradius, tree.offset, args.renderer_step_size, comm)
+        mask = oops.threshold_mask(weights, args.weight_thresh)
+        del weights
+    else:
+        raise ValueError(args.masking_mode)
+    del sig
+    tree.refine_from_mask(mask)
+    if tree.max_depth != args.init_grid_depth:
+        raise RuntimeError(f"empty mask: the tree has depth {tree.max_depth}, expected {args.init_grid_depth} "
+                           "(lower --weight_thresh / --alpha_thresh or check the bounding box)")
+    return mask
+
+
+def step2(args, tree, model, state, comm, seed=0):
+    """3-D antialiasing (:355-394, SH formats): every deepest-level cell gets the mean of the network output
+    at `samples_per_cell` uniform points inside it.  Nodes are sharded over the ranks and all-gathered."""
+    S = args.samples_per_cell
+    _, total = tree.max_depth_nodes()
+    per = (total + comm.world - 1) // comm.world
+    a, b = min(comm.rank * per, total), min((comm.rank + 1) * per, total)
+    chunk_nodes = max(args.chunk // (8 * S), 1) * 64
+    block = torch.zeros(per * 8, tree.data_dim, dtype=torch.float32, device=tree.device)
+    for n0 in range(a, b, chunk_nodes):
+        cnt = min(chunk_nodes, b - n0)
+        pts = tree.sample_max_depth_cells(S, first=n0, count=cnt, seed=seed)
+        rgb, sigma = model.eval_points_raw(state, pts.view(-1, 3))
+        ops.mean_over_samples(model.cfg, rgb, sigma, S, out=block[(n0 - a) * 8:(n0 - a + cnt) * 8])
+    if comm.is_dist:
+        block = comm.all_gather_cat(block)
+    tree.max_depth_data().copy_(block[: total * 8])
+
+
+def tree_center_radius(tree):
+    radius = 0.5 / tree.invradius
+    center = (1.0 - 2.0 * tree.offset) * radius
+    return center.tolist(), radius.tolist()
+
+
+def eval_octree(tree, dataset, args, comm=None, want_frames=False):
+    """eval_octree (octree/nerf/utils.py:448-497): mean PSNR of the octree renders of a split; images are
+    sharded over the ranks.  (SSIM / LPIPS are image-metric networks outside this path.)"""
+    comm = comm or dist.Comm()
+    r = VolumeRenderer(tree, step_size=args.renderer_step_size)
+    acc = torch.zeros(2, dtype=torch.float64, device=tree.device)
+    frames = []
+    for idx in range(comm.rank, dataset.size, comm.world):
+        gt = dataset.get_image(idx)["pixels"]
+        im = r.render_persp(torch.from_numpy(dataset.camtoworlds[idx]), width=dataset.w, height=dataset.h,
+                            fx=dataset.focal, fast=not args.no_early_stop)
+        sse, _ = oops.image_mse(im, gt.contiguous(), want_grad=False)
+        acc[0] += utils.compute_psnr(float(sse) / im.numel())
+        acc[1] += 1
+        if want_frames:
+            frames.append((idx, im.clamp(0, 1).cpu()))
+    comm.all_reduce_sum(acc)
+    return float(acc[0] / acc[1]), frames
+
+
+def _floats(text, name):
+    vals = [float(v) for v in str(text).split()]
+    if len(vals) == 1:
+        vals *= 3
+    if len(vals) != 3:
+        raise ValueError(f"--{name} takes one or three numbers")
+    return vals
+
+
+def define_flags():
+    """Flag names and defaults of octree/extraction.py:43-176 and octree/nerf/utils.py:211-219."""
     p = utils.define_flags()
-    p.add_argument("--output", type=str, default=None, help="npz with the sigma grid / mask")
-    p.add_argument("--center", type=float, nargs=3, default=[0.0, 0.0, 0.0])
-    p.add_argument("--radius", type=float, nargs=3, default=[1.5, 1.5, 1.5])     # extraction.py:76-79
-    p.add_argument("--init_grid_depth", type=int, default=8)
-    p.add_argument("--alpha_thresh", type=float, default=0.01)
-    p.add_argument("--scale_alpha_thresh", type=float, default=0.01)
-    p.add_argument("--autoscale", action="store_true")
-    args = p.parse_args(argv)
+    a = p.add_argument
+    a("--output", type=str, default="./tree.npz")
+    a("--center", type=str, default="0 0 0")
+    a("--radius", type=str, default="1.5")
+    a("--alpha_thresh", type=float, default=0.01)
+    a("--init_grid_depth", type=int, default=8)
+    a("--samples_per_cell", "-S", type=int, default=8)
+    a("--masking_mode", type=str, default="weight", choices=["sigma", "weight"])
+    a("--weight_thresh", type=float, default=0.001)
+    a("--autoscale", action="store_true")
+    a("--bbox_cube", action="store_true")
+    a("--bbox_scale", type=float, default=1.0)
+    a("--scale_alpha_thresh", type=float, default=0.01)
+    a("--tree_branch_n", type=int, default=2)
+    a("--eval", type=utils._bool, default=True)
+    a("--renderer_step_size", type=float, default=1e-4)
+    a("--no_early_stop", action="store_true")
+    return p
+
+
+def main(argv=None):
+    args = define_flags().parse_args(argv)
     utils.update_flags(args)
     if not torch.cuda.is_available():
         raise SystemExit("octree.extraction needs a ROCm GPU; the HIP path has no CPU fallback")
     comm = dist.init_from_env()
     torch.cuda.set_device(comm.local_rank)
     device = torch.device("cuda", comm.local_rank)
-    utils.check_flags(args, require_data=False, world_size=comm.world)
+    utils.check_flags(args, require_data=True, world_size=comm.world)
+    say = print if comm.rank == 0 else (lambda *a, **k: None)
+    say("* Loading NeRF", flush=True)
     model, state = models.get_model_state(args, device, restore=True)
-    center, radius = args.center, args.radius
+    dataset = datasets.get_dataset("train", args, device)
+    center, radius = _floats(args.center, "center"), _floats(args.radius, "radius")
     if args.autoscale:
+        say("* Step 0: Auto scale", flush=True)
         center, radius = auto_scale(model, state, center, radius, args.init_grid_depth, args.scale_alpha_thresh, comm)
-        if comm.rank == 0:
-            print("* Auto scale result center", center, "radius", radius, flush=True)
+        say("Autoscale result center", center, "radius", radius, flush=True)
+    radius = [r * args.bbox_scale for r in radius]
+    if args.bbox_cube:
+        radius = [max(radius)] * 3
+    data_dim = 1 + args.num_rgb_channels * (args.sh_deg + 1) ** 2
+    say("data dim is", data_dim, flush=True)
+    tree = N3Tree(N=args.tree_branch_n, data_dim=data_dim, init_refine=0, depth_limit=args.init_grid_depth,
+                  radius=radius, center=center, data_format=f"SH{(args.sh_deg + 1) ** 2}", map_location=device)
     reso = 2 ** (args.init_grid_depth + 1)
+    say("* Step 1: Grid eval", reso, flush=True)
+    torch.cuda.synchronize(); comm.barrier(); t0 = time.time()
+    mask = step1(args, tree, model, state, dataset, comm)
+    torch.cuda.synchronize(); comm.barrier(); t1 = time.time()
+    say(f"  {int(mask.sum())} / {reso ** 3} voxels kept ({args.masking_mode} mask); step 1 took {t1 - t0:.2f} s", flush=True)
+    say(tree, flush=True)
+    say("* Step 2: AA", args.samples_per_cell, flush=True)
+    step2(args, tree, model, state, comm, seed=args.seed)
+    tree.relu_sigma_()
+    tree.shrink_to_fit()
+    torch.cuda.synchronize(); comm.barrier(); t2 = time.time()
+    say(f"  step 2 took {t2 - t1:.2f} s", flush=True)
+    say(tree, flush=True)
     if comm.rank == 0:
-        print("* Step 1: Grid eval", reso, flush=True)
-    torch.cuda.synchronize(); comm.barrier()
-    t0 = time.time()
-    sig = grid_sigma(model, state, reso, center, radius, comm)
-    torch.cuda.synchronize(); comm.barrier()
-    dt = time.time() - t0
-    if comm.rank == 0:
-        flop = reso ** 3 * (1007104 if model.sh_deg == 3 else 1020928)
-        print(f"* grid eval: {reso ** 3} points in {dt:.3f} s = {reso ** 3 / dt / 1e6:.1f} Mpts/s "
-              f"({flop / dt / 1e12:.1f} TFLOP/s over {comm.world} GPU(s))", flush=True)
-    sigma_thresh = -np.log(1.0 - args.alpha_thresh) / (2.0 / reso)
-    mask = sig >= sigma_thresh
-    if comm.rank == 0:
-        print(f"* {int(mask.sum())} / {reso ** 3} voxels above sigma threshold {sigma_thresh:.4f}", flush=True)
-        if args.output:
-            np.savez(args.output, sigma=sig.cpu().numpy().reshape(reso, reso, reso), center=np.array(center),
-                     radius=np.array(radius), sigma_thresh=sigma_thresh)
+        base = os.path.dirname(args.output)
+        if base:
+            os.makedirs(base, exist_ok=True)
+        print("* Saving", args.output, flush=True)
+        tree.save(args.output, compress=False)
+    if args.eval:
+        test = datasets.get_dataset("test", args, device)
+        say("* Evaluation (before fine tune)", flush=True)
+        psnr, _ = eval_octree(tree, test, args, comm)
+        say("Average PSNR", psnr, flush=True)
     comm.shutdown()
-    return sig
+    return tree
 
 
 if __name__ == "__main__":

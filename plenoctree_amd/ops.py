@@ -314,10 +314,13 @@ def generate_rays(c2w, W, H, focal, pixel_ids=None, count=None):
     return o, d, v
 
 
-def mean_over_samples(cfg, raw_rgb, raw_sigma, samples_per_cell):
+def mean_over_samples(cfg, raw_rgb, raw_sigma, samples_per_cell, out=None):
     _require_gpu()
     n = raw_sigma.numel() // samples_per_cell
-    out = _new(n, rgb_channels(cfg) + 1, device=raw_sigma.device)
+    if out is None:
+        out = _new(n, rgb_channels(cfg) + 1, device=raw_sigma.device)
+    elif out.numel() != n * (rgb_channels(cfg) + 1):
+        raise PxoError("mean_over_samples: `out` has the wrong size")
     check(_lib.load().pxo_mean_over_samples(ctypes.byref(cfg), _f(raw_rgb), _f(raw_sigma.reshape(-1)), n,
                                             samples_per_cell, _f(out), _stream()), "pxo_mean_over_samples")
     return out

@@ -407,7 +407,7 @@ struct Marcher {
       const int bit = kBits - 1 - depth;
       cell = (int)(((X >> bit) & 1u) << 2 | ((Y >> bit) & 1u) << 1 | ((Z >> bit) & 1u));
       const int skip = child[(int64_t)node * 8 + cell];
-      if (skip == 0) break;
+      if (skip == 0 || depth >= kMaxD) break;          // depth bound: a malformed file cannot spin the descent
       node += skip;
       ++depth;
       stack[depth] = node;

@@ -1,7 +1,7 @@
 """Ray/pixel feeders for the NeRF-SH trainer.
 
-`Blender` follows the reference's loader (nerf_sh/nerf/datasets.py:189-232: transforms_*.json,
-RGBA composited on white, focal from camera_angle_x) and batch sampler (:149-167: one random
+`Blender` and `NSVF` follow the reference's loaders (nerf_sh/nerf/datasets.py:189-232: transforms_*.json,
+RGBA composited on white, focal from camera_angle_x; :491-552: intrinsics.txt + pose/ + rgb/) and batch sampler (:149-167: one random
 image, B random pixels with replacement).  `Synthetic` is the stand-in used where no dataset
 exists (the GPU box has none): the same Blender camera convention and sampler over an
 analytic scene whose pixel colours are a closed-form function of the ray, so targets are
@@ -166,7 +166,50 @@ class Blender(Dataset):
         return self.images[image_index][ray_indices.cpu()].to(self.device).contiguous()
 
 
-dataset_dict = {"blender": Blender, "synthetic": Synthetic}
+class NSVF(Dataset):
+    """NSVF-format loader used by the Tanks&Temples preset (reference nerf_sh/nerf/datasets.py:491-552;
+    bbox.txt as in octree/nerf/datasets.py:73-77): intrinsics.txt, pose/<split>_*.txt, rgb/<split>_*.png
+    with split prefix 0_ train, 1_ val, 2_ test (falling back to 1_ when there is no 2_)."""
+
+    def _load(self, args):
+        from PIL import Image
+        root = os.path.expanduser(args.data_dir)
+        K = np.loadtxt(os.path.join(root, "intrinsics.txt"))
+        pose_files = sorted(os.listdir(os.path.join(root, "pose")))
+        img_files = sorted(os.listdir(os.path.join(root, "rgb")))
+        prefix = {"train": "0_", "val": "1_", "test": "2_"}[self.split]
+        if self.split == "test" and not any(f.startswith("2_") for f in pose_files):
+            prefix = "1_"
+        pose_files = [f for f in pose_files if f.startswith(prefix)]
+        img_files = [f for f in img_files if f.startswith(prefix)]
+        if len(pose_files) != len(img_files):
+            raise ValueError(f"NSVF {root}: {len(img_files)} images but {len(pose_files)} poses for split {self.split}")
+        cam_trans = np.diag(np.array([1, -1, -1, 1], dtype=np.float32))       # OpenCV -> OpenGL axes (:517)
+        images, cams = [], []
+        for img_name, pose_name in zip(img_files, pose_files):
+            img = Image.open(os.path.join(root, "rgb", img_name))
+            if args.factor > 1:
+                img = img.resize((img.width // args.factor, img.height // args.factor), Image.BOX)  # area filter
+            image = np.asarray(img, dtype=np.float32) / 255.0
+            cams.append(np.loadtxt(os.path.join(root, "pose", pose_name)) @ cam_trans)
+            if image.shape[-1] == 4:
+                image = image[..., :3] * image[..., -1:] + (1.0 - image[..., -1:]) if self.white_bkgd else image[..., :3]
+            images.append(image)
+        images = np.stack(images, 0)
+        self.n_examples, self.h, self.w = images.shape[:3]
+        self.camtoworlds = np.stack(cams, 0).astype(np.float32)
+        self.focal = float(K[0, 0] + K[1, 1]) * 0.5                            # :548-551
+        if args.factor > 1:
+            self.focal /= args.factor
+        bbox_path = os.path.join(root, "bbox.txt")
+        self.bbox = np.loadtxt(bbox_path)[:-1] if os.path.isfile(bbox_path) else None
+        self.images = torch.from_numpy(images.reshape(self.n_examples, -1, 3))
+
+    def _pixels_for(self, image_index, ray_indices, rays):
+        return self.images[image_index][ray_indices.cpu()].to(self.device).contiguous()
+
+
+dataset_dict = {"blender": Blender, "nsvf": NSVF, "synthetic": Synthetic}
 
 
 def get_dataset(split, args, device, batch_size=None):

@@ -183,6 +183,8 @@ def define_flags():
     a("--samples_per_cell", "-S", type=int, default=8)
     a("--masking_mode", type=str, default="weight", choices=["sigma", "weight"])
     a("--weight_thresh", type=float, default=0.001)
+    a("--bbox_from_data", action="store_true")
+    a("--data_bbox_scale", type=float, default=1.0)
     a("--autoscale", action="store_true")
     a("--bbox_cube", action="store_true")
     a("--bbox_scale", type=float, default=1.0)
@@ -207,7 +209,15 @@ def main(argv=None):
     say("* Loading NeRF", flush=True)
     model, state = models.get_model_state(args, device, restore=True)
     dataset = datasets.get_dataset("train", args, device)
-    center, radius = _floats(args.center, "center"), _floats(args.radius, "radius")
+    if args.bbox_from_data:                                  # :447-451 (NSVF datasets carry bbox.txt)
+        bbox = getattr(dataset, "bbox", None)
+        if bbox is None:
+            raise ValueError("--bbox_from_data needs a dataset with bbox.txt (NSVF format)")
+        center = ((bbox[:3] + bbox[3:6]) * 0.5).tolist()
+        radius = ((bbox[3:6] - bbox[:3]) * 0.5 * args.data_bbox_scale).tolist()
+        say("Bounding box from data: c", center, "r", radius, flush=True)
+    else:
+        center, radius = _floats(args.center, "center"), _floats(args.radius, "radius")
     if args.autoscale:
         say("* Step 0: Auto scale", flush=True)
         center, radius = auto_scale(model, state, center, radius, args.init_grid_depth, args.scale_alpha_thresh, comm)

@@ -84,6 +84,44 @@ def run_validation(renderer, c2ws, images, H, W, focal, comm):
     return float(acc[0] / acc[1])
 
 
+def fit(args, tree, train, val, H, W, focal, comm, say=print):
+    """The epoch loop of octree/optimization.py:189-243.  train/val = (c2w [n,4,4], list of [H,W,3] images).
+    Rank r takes image j0 + r of every group of `world` images; the group's gradients are summed with one
+    all-reduce and applied as one step on their mean.  Returns (history, best tree on the CPU or None)."""
+    (train_c2w, train_gt), (test_c2w, test_gt) = train, val
+    renderer = VolumeRenderer(tree, step_size=args.renderer_step_size)
+    opt = TreeOptimizer(tree, args)
+    say("Using SGD, lr" if args.sgd else "Using Adam, lr", args.lr, flush=True)
+    best = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
+    say("** initial val psnr ", best, flush=True)
+    history, best_tree = [(0, None, best)], None
+    n_train = len(train_gt)
+    for epoch in range(args.num_epochs):
+        tpsnr = torch.zeros(1, dtype=torch.float64, device=tree.device)
+        for j0 in range(0, n_train, comm.world):
+            j = j0 + comm.rank
+            opt.zero_grad()
+            if j < n_train:
+                sse = train_image(renderer, opt, train_c2w[j], train_gt[j], H, W, focal)
+                tpsnr += utils.compute_psnr(float(sse) / (H * W * 3))
+            n_imgs = min(comm.world, n_train - j0)
+            comm.all_reduce_sum(opt.grad)
+            opt.step(grad_scale=1.0 / n_imgs)
+        comm.all_reduce_sum(tpsnr)
+        train_psnr = float(tpsnr) / n_train
+        say("epoch", epoch, "** train_psnr", train_psnr, flush=True)
+        if epoch % args.val_interval == args.val_interval - 1 or epoch == args.num_epochs - 1:
+            val_psnr = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
+            say("** val psnr ", val_psnr, "best", best, flush=True)
+            history.append((epoch + 1, train_psnr, val_psnr))
+            if val_psnr > best:
+                best, best_tree = val_psnr, tree.clone(device="cpu")
+            elif not args.continue_on_decrease:
+                say("Stop since overfitting", flush=True)
+                break
+    return history, best_tree
+
+
 def main(argv=None):
     args = define_flags().parse_args(argv)
     utils.update_flags(args)
@@ -113,36 +151,7 @@ def main(argv=None):
         _, test_c2w, test_gt = get_data("test" if args.dataset == "synthetic" else "val")
     say("N3Tree load", flush=True)
     tree = N3Tree.load(args.input, map_location=device)
-    renderer = VolumeRenderer(tree, step_size=args.renderer_step_size)
-    opt = TreeOptimizer(tree, args)
-    say("Using SGD, lr" if args.sgd else "Using Adam, lr", args.lr, flush=True)
-    best = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
-    say("** initial val psnr ", best, flush=True)
-    history, best_tree = [(0, None, best)], None
-    n_train = len(train_gt)
-    for epoch in range(args.num_epochs):
-        tpsnr = torch.zeros(1, dtype=torch.float64, device=device)
-        for j0 in range(0, n_train, comm.world):
-            j = j0 + comm.rank
-            opt.zero_grad()
-            if j < n_train:
-                sse = train_image(renderer, opt, train_c2w[j], train_gt[j], H, W, focal)
-                tpsnr += utils.compute_psnr(float(sse) / (H * W * 3))
-            n_imgs = min(comm.world, n_train - j0)
-            comm.all_reduce_sum(opt.grad)
-            opt.step(grad_scale=1.0 / n_imgs)
-        comm.all_reduce_sum(tpsnr)
-        train_psnr = float(tpsnr) / n_train
-        say("epoch", epoch, "** train_psnr", train_psnr, flush=True)
-        if epoch % args.val_interval == args.val_interval - 1 or epoch == args.num_epochs - 1:
-            val = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
-            say("** val psnr ", val, "best", best, flush=True)
-            history.append((epoch + 1, train_psnr, val))
-            if val > best:
-                best, best_tree = val, tree.clone(device="cpu")
-            elif not args.continue_on_decrease:
-                say("Stop since overfitting", flush=True)
-                break
+    history, best_tree = fit(args, tree, (train_c2w, train_gt), (test_c2w, test_gt), H, W, focal, comm, say)
     if not args.nosave and comm.rank == 0:
         if best_tree is not None:
             print("Saving best model to", args.output, flush=True)

@@ -98,3 +98,40 @@ def test_blender_loader(tmp_path):
     np.testing.assert_allclose(ds.images[1].numpy().reshape(8, 8, 3), want, rtol=1e-6)
     b = next(ds)
     assert b["pixels"].shape == (16, 3)
+
+
+def test_nsvf_loader_on_a_synthetic_directory(tmp_path):
+    """NSVF-format directory (reference nerf_sh/nerf/datasets.py:491-552): split prefixes, OpenCV->OpenGL pose
+    flip, RGBA on white, focal from intrinsics, bbox.txt, test split falling back to 1_."""
+    from PIL import Image
+    root = tmp_path / "scene"
+    (root / "pose").mkdir(parents=True); (root / "rgb").mkdir()
+    K = np.eye(4); K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 30.0, 32.0, 4.0, 3.0
+    np.savetxt(root / "intrinsics.txt", K)
+    np.savetxt(root / "bbox.txt", np.array([[-1.0, -2.0, -3.0, 1.0, 2.0, 3.0, 0.4]]))
+    rs = np.random.RandomState(0)
+    poses = {}
+    for name in ("0_0000", "0_0001", "0_0002", "1_0000"):
+        pose = np.eye(4); pose[:3, :3] = np.linalg.qr(rs.randn(3, 3))[0]; pose[:3, 3] = rs.randn(3)
+        poses[name] = pose
+        np.savetxt(root / "pose" / f"{name}.txt", pose)
+        rgba = (rs.rand(6, 8, 4) * 255).astype(np.uint8)
+        Image.fromarray(rgba, "RGBA").save(root / "rgb" / f"{name}.png")
+        poses[name + "_img"] = rgba
+    a = _args(["--config", "tt", "--train_dir", "x", "--data_dir", str(root)])
+    utils.update_flags(a); a.factor = 0
+    ds = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=16)
+    assert (ds.size, ds.h, ds.w) == (3, 6, 8) and ds.focal == pytest.approx(31.0)
+    np.testing.assert_allclose(ds.bbox, [-1, -2, -3, 1, 2, 3])
+    np.testing.assert_allclose(ds.camtoworlds[1], poses["0_0001"] @ np.diag([1.0, -1.0, -1.0, 1.0]), rtol=1e-6)
+    rgba = poses["0_0002_img"].astype(np.float32) / 255.0
+    want = rgba[..., :3] * rgba[..., 3:] + (1.0 - rgba[..., 3:])
+    np.testing.assert_allclose(ds.get_image(2)["pixels"].numpy(), want, atol=1e-6)
+    batch = next(ds)
+    assert batch["pixels"].shape == (16, 3) and batch["rays"].origins.shape == (16, 3)
+    test = datasets.get_dataset("test", a, torch.device("cpu"))
+    assert test.size == 1                                        # no 2_ files: falls back to 1_
+    np.testing.assert_allclose(test.camtoworlds[0], poses["1_0000"] @ np.diag([1.0, -1.0, -1.0, 1.0]), rtol=1e-6)
+    a.factor = 2
+    half = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=4)
+    assert (half.h, half.w) == (3, 4) and half.focal == pytest.approx(15.5)

@@ -29,6 +29,7 @@ def main(argv=None):
     per_rank = args.batch_size // comm.world
     dataset = datasets.get_dataset("train", args, device, batch_size=per_rank)
     dataset.rng = np.random.RandomState(20201473 + comm.rank)      # train.py:128
+    dataset.seed = 20201473 + comm.rank
     test_dataset = datasets.get_dataset("test", args, device)
     model, state = models.get_model_state(args, device, restore=True)
     init_step = state.step + 1                                       # train.py:176

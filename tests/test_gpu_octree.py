@@ -320,3 +320,56 @@ def test_extraction_pipeline_end_to_end(tmp_path):
                                        "--lr", "2e4", "--continue_on_decrease"])
     train_psnrs = [h[1] for h in hist if h[1] is not None]
     assert len(train_psnrs) == 3 and train_psnrs[-1] > train_psnrs[0], hist
+
+
+def test_octree_full_size_properties():
+    """Reference sizes (depth 8 tree over a 512^3 mask, 800x800 view): properties that need no oracle --
+    camera mode == explicit-ray mode, bit-identical repeats, early-stop within its thresholds of the exact
+    render, gradient linear in grad_out and zero where nothing was seen."""
+    oops = _oops(); dev = _gpu()
+    from plenoctree_amd import ops
+    from plenoctree_amd.octree import svox
+    depth, reso, K = 8, 512, 16
+    ax = ((torch.arange(reso, device=dev, dtype=torch.float32) + 0.5) / reso - 0.5) * 3.0
+    d2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + (ax[None, None, :] * 1.3) ** 2
+    mask = ((d2.sqrt() - 0.8).abs() < 0.02).to(torch.uint8).reshape(-1)         # thin ellipsoidal shell
+    tree = svox.N3Tree(N=2, data_dim=3 * K + 1, depth_limit=depth, radius=1.5, center=[0, 0, 0], data_format="SH16",
+                       map_location=dev)
+    tree.refine_from_mask(mask)
+    assert tree.max_depth == depth and tree.n_internal > 100000
+    leaf = tree.max_depth_data()
+    g = torch.Generator(device=dev).manual_seed(0)
+    leaf.copy_(torch.randn(leaf.shape, device=dev, generator=g) * 0.5)
+    leaf[:, -1] = (torch.rand(leaf.shape[0], device=dev, generator=g) - 0.3) * 60.0
+    W = H = 800
+    focal = 0.5 * W / math.tan(0.5 * 0.6911112)
+    c2w = torch.from_numpy(_pose(35.0, 25.0, 4.0311)).to(dev)
+    r = svox.VolumeRenderer(tree, step_size=1e-4)
+    im = r.render_persp(c2w, width=W, height=H, fx=focal)
+    assert im.shape == (H, W, 3) and bool(torch.isfinite(im).all())
+    seen = (im - 1.0).abs().amax(dim=-1) > 1e-3
+    assert 0.05 < float(seen.float().mean()) < 0.6                            # the shell covers part of the view
+    assert torch.equal(im, r.render_persp(c2w, width=W, height=H, fx=focal))  # deterministic
+    o, d, v = ops.generate_rays(c2w, W, H, focal)
+    im_rays = r.forward(o, v, v).reshape(H, W, 3)                             # unit directions
+    close("camera vs explicit rays", im_rays, im, rtol=0, atol=2e-5)
+    fast = r.render_persp(c2w, width=W, height=H, fx=focal, fast=True)
+    assert float((fast - im).abs().max()) < 0.03                              # sigma/stop thresholds of 1e-2
+    # gradient: linear in grad_out, confined to leaves that rays reached
+    g1, g2 = torch.randn(H, W, 3, device=dev, generator=g), torch.randn(H, W, 3, device=dev, generator=g)
+    opts = r._opts(False)
+    grads = []
+    for go in (g1, g2, g1 + g2):
+        gd = torch.zeros_like(tree.data)
+        oops.octree_render_persp_bwd(tree.view(), c2w, W, H, focal, opts, go.contiguous(), gd)
+        grads.append(gd)
+    scale = float(grads[2].abs().max())
+    assert scale > 0
+    assert float((grads[0] + grads[1] - grads[2]).abs().max()) < 2e-4 * scale
+    node0, _ = tree.max_depth_nodes()
+    assert not bool(grads[2][:node0].any())                                   # shallower leaves hold sigma = 0
+    hit = grads[2][node0:].abs().amax(dim=-1) > 0
+    assert 0.01 < float(hit.float().mean()) < 0.9
+    # a pixel that misses the volume gets no gradient and the background colour
+    miss = ~seen
+    assert bool(miss.any()) and float((im[miss] - 1.0).abs().max()) <= 1e-3

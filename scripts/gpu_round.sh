@@ -34,5 +34,6 @@ if [ "${DO_PROF:-1}" = "1" ]; then
   cd "$R"
   find gpurun_out/prof gpurun_out/pmc* -type f | head -30
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
+  f=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/gap_analysis.py "$f" | tee gpurun_out/gaps.txt
   find gpurun_out -name "*.csv" -size +30M -delete
 fi

@@ -11,3 +11,17 @@ if [ "${DO_BENCH:-1}" = "1" ]; then
   timeout 300 python scripts/octree_bench.py ${BENCH_ARGS:-} > gpurun_out/octree_bench.json 2> gpurun_out/octree_bench.err
   echo "octree_bench exit $?"; cat gpurun_out/octree_bench.json; tail -5 gpurun_out/octree_bench.err
 fi
+if [ "${DO_PROF:-0}" = "1" ]; then
+  R=$PWD; cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/oprof" -o obench -- python "$R/scripts/octree_bench.py" --cams 4 > "$R/gpurun_out/oprof_bench.json" 2> "$R/gpurun_out/oprof.err"
+  echo "octree rocprof exit $?"
+  i=0
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/gpurun_out/opmc$i" -o pmc -- python "$R/scripts/octree_bench.py" --cams 2 > /dev/null 2> "$R/gpurun_out/opmc$i.err"
+    echo "octree pmc pass $i exit $?"
+  done
+  cd "$R"
+  find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
+  python scripts/summarize_octree_prof.py gpurun_out gpurun_out tmp
+fi

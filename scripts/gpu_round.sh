@@ -26,7 +26,7 @@ if [ "${DO_PROF:-1}" = "1" ]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
   echo "rocprof exit $?"
   i=0
-  for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  [ "${DO_PMC:-1}" = "1" ] && for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$R/gpurun_out/pmc$i.err"
     echo "pmc pass $i exit $?"

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Condense the rocprofv3 output of scripts/octree_bench.py (gpurun_out/oprof, opmc1, opmc2) into
+profiles/<tag>_octree_kernels.md: per-kernel launches, average duration, HBM bytes per launch (PMC
+FETCH_SIZE x2 per the gfx950 correction in MI355X_MICROARCH.md, WRITE_SIZE) and the bandwidth they imply."""
+import collections
+import csv
+import os
+import sys
+
+
+def pmc(path, counter):
+    tot, n, dur, seen = collections.defaultdict(float), collections.Counter(), collections.defaultdict(float), set()
+    if not os.path.exists(path):
+        return {}, {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "pxo::" not in k or r["Counter_Name"] != counter:
+                continue
+            tot[k] += float(r["Counter_Value"])
+            key = (k, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key); n[k] += 1
+                dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    return {k: tot[k] / n[k] for k in tot}, {k: dur[k] / n[k] for k in dur}
+
+
+def main(src, dst_dir, tag):
+    stats = {}
+    ks = os.path.join(src, "oprof", "obench_kernel_stats.csv")
+    with open(ks) as f:
+        for r in csv.DictReader(f):
+            k = r["Name"].split("(")[0].replace("void ", "")
+            if "pxo::" in k:
+                stats[k] = (int(r["Calls"]), float(r["AverageNs"]) * 1e-6, float(r["Percentage"]))
+    rd, _ = pmc(os.path.join(src, "opmc1", "pmc_counter_collection.csv"), "FETCH_SIZE")
+    wr, _ = pmc(os.path.join(src, "opmc2", "pmc_counter_collection.csv"), "WRITE_SIZE")
+    out = [f"# PlenOctree-side kernels `{tag}` (rocprofv3 --kernel-trace --stats of scripts/octree_bench.py; HBM bytes from",
+           "# separate --pmc FETCH_SIZE / WRITE_SIZE passes, KiB, FETCH x2 on gfx950)\n",
+           "| kernel | launches | avg ms | % of GPU time | HBM read MB / launch | HBM write MB / launch | HBM GB/s |", "|---|---|---|---|---|---|---|"]
+    for k, (calls, ms, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+        r = rd.get(k, float("nan")) * 2 / 1024
+        w = wr.get(k, float("nan")) / 1024
+        out.append(f"| `{k[:60]}` | {calls} | {ms:.3f} | {pct:.1f} | {r:.1f} | {w:.1f} | {(r + w) / ms:.0f} |")
+    os.makedirs(dst_dir, exist_ok=True)
+    with open(os.path.join(dst_dir, f"{tag}_octree_kernels.md"), "w") as g:
+        g.write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "profiles",
+         sys.argv[3] if len(sys.argv) > 3 else "r01")

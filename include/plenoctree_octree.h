@@ -89,10 +89,12 @@ int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream
 /* For each of the n_cams cameras (c2w_all: [n_cams,12] device) and every pixel, marches the ray through
  * the dense sigma grid [reso^3] and keeps, per voxel, the maximum compositing weight
  * light * (1 - exp(-dt * sigma)).  grid_weight [reso^3] must be zero-initialised by the caller for the
- * first call; successive calls accumulate the maximum (torch.max over cameras, :206-212). */
+ * first call; successive calls accumulate the maximum (torch.max over cameras, :206-212).
+ * ws: pxo_grid_weight_workspace_bytes(reso) bytes (brick-ordered copies of the grid and the weights). */
+int pxo_grid_weight_workspace_bytes(int reso, size_t* bytes);
 int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx,
                            float fy, int width, int height, const PxoRenderOpts* opts, const float offset[3],
-                           const float invradius[3], float* grid_weight, void* stream);
+                           const float invradius[3], float* grid_weight, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- octree volume renderer  (VolumeRenderer.render_persp / render; octree/nerf/utils.py:456-474,
  *      octree/optimization.py:174-216) ---- */
@@ -105,10 +107,12 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
                           void* stream);
 /* Gradient of sum(out_rgb * grad_out) w.r.t. tree->data, ACCUMULATED (atomic adds) into grad_data
  * [n_internal,2,2,2,D] -- zero it first (optimizer.zero_grad(), octree/optimization.py:221-224).
- * Training semantics: exact marching (stop_thresh is ignored: no early-stop rescale). */
+ * Training semantics: exact marching (stop_thresh is ignored: no early-stop rescale).
+ * out_rgb: the [B,3] result of pxo_octree_render_fwd for the same rays with the same exact options, or NULL
+ * (the kernel then re-marches once more to recover it). */
 int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
-                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* grad_out,
-                          float* grad_data, void* stream);
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
+                          const float* grad_out, float* grad_data, void* stream);
 
 /* mse = mean((clamp(im,0,1) - gt)^2) and its gradient w.r.t. im  (octree/optimization.py:217-219);
  * n = number of floats.  sse_out: device scalar receiving sum of squares (mse = sse/n); grad may be NULL. */

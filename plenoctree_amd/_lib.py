@@ -112,12 +112,13 @@ SIGNATURES = {
     "pxo_tree_build": (c_int, [P, c_size_t, c_int, POINTER(c_int64), P, P, P]),
     "pxo_tree_sample_cells": (c_int, [P, c_int64, c_int64, c_int, P, F3, F3, P, P]),
     "pxo_tree_relu_sigma": (c_int, [P, c_int64, c_int, P]),
+    "pxo_grid_weight_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "pxo_grid_weight_render": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
-                                       F3, F3, P, P]),
+                                       F3, F3, P, P, c_size_t, P]),
     "pxo_octree_render_fwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
-                                      POINTER(PxoRenderOpts), P, P, P]),
+                                      POINTER(PxoRenderOpts), P, P, P, P]),
     "pxo_image_mse": (c_int, [P, P, c_int64, P, P, P]),
     "pxo_sgd_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_int, P]),
 }

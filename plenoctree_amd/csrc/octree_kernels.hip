@@ -289,6 +289,33 @@ __device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.
 // ------------------------------------------------------------------------------------------
 struct Vec3 { float v[3]; };
 
+// sigma and the weights are walked in 4x4x4 bricks (256 B = two cache lines per brick): a marching ray takes
+// several samples per brick and the 8x8-pixel footprint of a wave spans only a few bricks, whereas in the
+// x-slowest layout nearly every sample of every lane touches its own line (PMC: 72 GB fetched per two
+// cameras against 4.6 GB of 4-byte samples; profiles/r01_octree_kernels.md).
+__host__ __device__ inline int64_t brick_index(int x, int y, int z, int nb) {
+  return ((((int64_t)(x >> 2) * nb + (y >> 2)) * nb + (z >> 2)) << 6) | ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
+}
+
+__global__ void brick_sigma_kernel(const float* __restrict__ lin, int reso, float* __restrict__ bricked) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;       // bricked index
+  if (i >= (int64_t)reso * reso * reso) return;
+  const int nb = reso >> 2;
+  const int l = (int)(i & 63);
+  const int64_t b = i >> 6;
+  const int bz = (int)(b % nb), by = (int)((b / nb) % nb), bx = (int)(b / ((int64_t)nb * nb));
+  const int x = bx * 4 + (l >> 4), y = by * 4 + ((l >> 2) & 3), z = bz * 4 + (l & 3);
+  bricked[i] = lin[((int64_t)x * reso + y) * reso + z];
+}
+
+__global__ void unbrick_max_kernel(const float* __restrict__ bricked, int reso, float* __restrict__ lin) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;       // linear index
+  if (i >= (int64_t)reso * reso * reso) return;
+  const int z = (int)(i % reso), y = (int)((i / reso) % reso), x = (int)(i / ((int64_t)reso * reso));
+  lin[i] = fmaxf(lin[i], bricked[brick_index(x, y, z, reso >> 2)]);
+}
+
+template <bool BRICK>
 __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restrict__ sigma, int reso,
                                                            const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
                                                            int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
     float s0, s1;
     dda_unit(local, r.invdir, s0, s1);
     const float delta_t = (s1 - s0) / cube + opt.step_size;
-    const int64_t idx = ((int64_t)c[0] * reso + c[1]) * reso + c[2];
+    const int64_t idx = BRICK ? brick_index(c[0], c[1], c[2], reso >> 2) : ((int64_t)c[0] * reso + c[1]) * reso + c[2];
     const float sg = sigma[idx];
     if (sg > opt.sigma_thresh) {
       const float att = expf(-(delta_t * r.delta_scale) * sg);
@@ -421,6 +448,7 @@ struct Marcher {
 // MODE 0: forward (writes out_rgb).  MODE 1: gradient w.r.t. tree data (two marches per ray).
 template <int MODE>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArgs A, float* __restrict__ out_rgb,
+                                                                        const float* __restrict__ fwd_rgb,
                                                                         const float* __restrict__ grad_out,
                                                                         float* __restrict__ grad_data) {
   __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
@@ -495,9 +523,14 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     for (int c = 0; c < 3; ++c) g[c] = grad_out[ray * 3 + c];
   }
   float accum = 0.0f;                          // MODE 1: sum_c g_c * out_c, then the part behind the sample
+  int first_pass = 0;
+  if (MODE == 1 && fwd_rgb != nullptr) {       // the caller kept the (exact) forward image: no first march
+    accum = (g[0] * fwd_rgb[ray * 3] + g[1] * fwd_rgb[ray * 3 + 1]) + g[2] * fwd_rgb[ray * 3 + 2];
+    first_pass = 1;
+  }
 
   // pass 0 composites; in MODE 1 pass 1 re-marches and scatters the gradient
-  for (int pass = 0; pass <= MODE; ++pass) {
+  for (int pass = first_pass; pass <= MODE; ++pass) {
     Marcher mk;
     mk.init(s_stack[row]);
     float t = r.tmin, light = 1.0f;
@@ -743,9 +776,15 @@ static int check_opts(const PxoRenderOpts* o, const char* who) {
   return PXO_OK;
 }
 
+int pxo_grid_weight_workspace_bytes(int reso, size_t* bytes) {
+  PXO_REQUIRE(reso >= 1 && reso <= 2048 && bytes, "pxo_grid_weight_workspace_bytes: bad arguments");
+  *bytes = (reso % 4 == 0) ? (size_t)2 * reso * reso * reso * sizeof(float) : 0;
+  return PXO_OK;
+}
+
 int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
                            int width, int height, const PxoRenderOpts* opts, const float offset[3],
-                           const float invradius[3], float* grid_weight, void* stream) {
+                           const float invradius[3], float* grid_weight, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_opts(opts, "pxo_grid_weight_render")) return rc;
   PXO_REQUIRE(reso >= 1 && reso <= 2048 && n_cams >= 0 && width >= 1 && height >= 1, "pxo_grid_weight_render: bad sizes");
   PXO_REQUIRE(fx > 0.0f && fy > 0.0f, "pxo_grid_weight_render: focal length must be > 0");
@@ -754,8 +793,29 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   Vec3 o{{offset[0], offset[1], offset[2]}}, ir{{invradius[0], invradius[1], invradius[2]}};
   const int64_t tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
   PXO_REQUIRE(tiles * n_cams < ((int64_t)1 << 31), "pxo_grid_weight_render: too many tiles for one launch");
-  hipLaunchKernelGGL(grid_weight_kernel, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, (hipStream_t)stream, sigma_grid, reso,
-                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(grid_weight));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)reso * reso * reso;
+  if (reso % 4 != 0) {   // grids that do not tile into bricks (never the case for 2^(depth+1), depth >= 1)
+    hipLaunchKernelGGL(grid_weight_kernel<false>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, sigma_grid, reso, c2w_all,
+                       n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(grid_weight));
+    return check_launch("grid_weight_render");
+  }
+  const size_t need = (size_t)2 * n * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    set_error("pxo_grid_weight_render: workspace %zu < %zu", ws_bytes, need);
+    return PXO_ERR_WORKSPACE;
+  }
+  float* sigma_b = reinterpret_cast<float*>(ws);
+  float* weight_b = sigma_b + n;
+  if (hipMemsetAsync(weight_b, 0, (size_t)n * sizeof(float), s) != hipSuccess) {
+    set_error("pxo_grid_weight_render: hipMemsetAsync failed");
+    return PXO_ERR_HIP;
+  }
+  hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, sigma_grid, reso, sigma_b);
+  hipLaunchKernelGGL(grid_weight_kernel<true>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, (const float*)sigma_b, reso,
+                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
+  hipLaunchKernelGGL(unbrick_max_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, (const float*)weight_b, reso,
+                     grid_weight);
   return check_launch("grid_weight_render");
 }
 
@@ -799,20 +859,20 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
   hipLaunchKernelGGL(octree_render_kernel<0>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb,
-                     (const float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   return check_launch("octree_render_fwd");
 }
 
 int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
-                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* grad_out,
-                          float* grad_data, void* stream) {
+                          const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
+                          const float* grad_out, float* grad_data, void* stream) {
   RenderArgs A;
   unsigned grid;
   if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", A, grid)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(grad_out && grad_data, "pxo_octree_render_bwd: null pointer");
   hipLaunchKernelGGL(octree_render_kernel<1>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr,
-                     grad_out, grad_data);
+                     out_rgb, grad_out, grad_data);
   return check_launch("octree_render_bwd");
 }
 

@@ -69,7 +69,7 @@ def train_image(renderer, opt, c2w, gt, H, W, focal):
     """One image: accumulates d mse / d data into opt.grad and returns the device scalar sum of squares."""
     im = renderer.render_persp(c2w, width=W, height=H, fx=focal, fast=False)
     sse, g = oops.image_mse(im, gt, want_grad=True)
-    oops.octree_render_persp_bwd(renderer.tree.view(), c2w, W, H, focal, renderer._opts(False), g, opt.grad)
+    oops.octree_render_persp_bwd(renderer.tree.view(), c2w, W, H, focal, renderer._opts(False), g, opt.grad, out_rgb=im)
     return sse
 
 

@@ -228,15 +228,18 @@ class _RenderPersp(torch.autograd.Function):
     def forward(ctx, data, renderer, c2w, width, height, fx, fy, opts):
         tree = renderer.tree
         ctx.args = (renderer, c2w, width, height, fx, fy, opts)
-        return oops.octree_render_persp(oops.tree_view(tree.child, data, tree.offset, tree.invradius), c2w, width, height, fx,
-                                        opts, fy)
+        out = oops.octree_render_persp(oops.tree_view(tree.child, data, tree.offset, tree.invradius), c2w, width, height, fx,
+                                       opts, fy)
+        ctx.save_for_backward(out)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         renderer, c2w, width, height, fx, fy, opts = ctx.args
         tree = renderer.tree
         grad = torch.zeros_like(tree.data)
-        oops.octree_render_persp_bwd(tree.view(), c2w, width, height, fx, opts, grad_out.contiguous(), grad, fy)
+        out, = ctx.saved_tensors
+        oops.octree_render_persp_bwd(tree.view(), c2w, width, height, fx, opts, grad_out.contiguous(), grad, fy, out_rgb=out)
         return grad, None, None, None, None, None, None, None
 
 

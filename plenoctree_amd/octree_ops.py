@@ -81,13 +81,17 @@ def tree_relu_sigma(data):
 def grid_weight_render(sigma_grid, reso, c2w_all, fx, fy, width, height, opts, offset, invradius, grid_weight=None):
     """Per-voxel maximum compositing weight over all pixels of the given cameras (c2w_all [n,3,4] or [n,4,4])."""
     _require_gpu()
+    lib = _lib.load()
     dev = sigma_grid.device
     c2w = c2w_all[:, :3, :4].contiguous().to(device=dev, dtype=torch.float32)
     if grid_weight is None:
         grid_weight = torch.zeros(reso ** 3, dtype=torch.float32, device=dev)
-    check(_lib.load().pxo_grid_weight_render(_f(sigma_grid.reshape(-1)), reso, _f(c2w), c2w.shape[0], float(fx), float(fy),
-                                             int(width), int(height), ctypes.byref(opts), _vec3(offset),
-                                             _vec3(invradius), _f(grid_weight), _stream()), "pxo_grid_weight_render")
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pxo_grid_weight_workspace_bytes(reso, ctypes.byref(nbytes)), "pxo_grid_weight_workspace_bytes")
+    ws = _new(max(nbytes.value, 16), device=dev, dtype=torch.uint8)
+    check(lib.pxo_grid_weight_render(_f(sigma_grid.reshape(-1)), reso, _f(c2w), c2w.shape[0], float(fx), float(fy),
+                                     int(width), int(height), ctypes.byref(opts), _vec3(offset), _vec3(invradius),
+                                     _f(grid_weight), _p(ws), nbytes.value, _stream()), "pxo_grid_weight_render")
     return grid_weight
 
 
@@ -125,11 +129,13 @@ def octree_render_persp(tree, c2w, width, height, fx, opts, fy=None):
     return out
 
 
-def octree_render_persp_bwd(tree, c2w, width, height, fx, opts, grad_out, grad_data, fy=None):
+def octree_render_persp_bwd(tree, c2w, width, height, fx, opts, grad_out, grad_data, fy=None, out_rgb=None):
+    """Accumulates d sum(image * grad_out) / d data into grad_data; `out_rgb` = the exact forward image of the same
+    camera (saves one of the two marches) or None."""
     _require_gpu()
     cam, keep = _camera(c2w, width, height, fx, fy)
     check(_lib.load().pxo_octree_render_bwd(ctypes.byref(tree), ctypes.byref(cam), None, None, None, width * height,
-                                            ctypes.byref(opts), _f(grad_out), _f(grad_data), _stream()),
+                                            ctypes.byref(opts), _f(out_rgb), _f(grad_out), _f(grad_data), _stream()),
           "pxo_octree_render_bwd")
     return grad_data
 
@@ -144,11 +150,11 @@ def octree_render_rays(tree, origins, dirs, viewdirs, opts):
     return out
 
 
-def octree_render_rays_bwd(tree, origins, dirs, viewdirs, opts, grad_out, grad_data):
+def octree_render_rays_bwd(tree, origins, dirs, viewdirs, opts, grad_out, grad_data, out_rgb=None):
     _require_gpu()
     check(_lib.load().pxo_octree_render_bwd(ctypes.byref(tree), None, _f(origins), _f(dirs), _f(viewdirs),
-                                            origins.shape[0], ctypes.byref(opts), _f(grad_out), _f(grad_data), _stream()),
-          "pxo_octree_render_bwd")
+                                            origins.shape[0], ctypes.byref(opts), _f(out_rgb), _f(grad_out), _f(grad_data),
+                                            _stream()), "pxo_octree_render_bwd")
     return grad_data
 
 

@@ -93,13 +93,17 @@ def main():
     gt = torch.rand_like(im)
     grad = torch.zeros_like(tree.data)
 
-    def bwd():
-        for c in cams:
-            _, g = oops.image_mse(im, gt)
-            oops.octree_render_persp_bwd(tree.view(), c, W, H, focal, r._opts(False), g, grad)
-    ms = timed(bwd, reps=2) / a.cams
-    out["render_bwd_ms_per_image"] = ms
-    out["render_bwd_Mrays_per_s"] = W * H / ms / 1e3
+    ims = [r.render_persp(c, width=W, height=H, fx=focal) for c in cams]
+
+    def bwd(reuse):
+        for c, imc in zip(cams, ims):
+            _, g = oops.image_mse(imc, gt)
+            oops.octree_render_persp_bwd(tree.view(), c, W, H, focal, r._opts(False), g, grad, out_rgb=imc if reuse else None)
+    for reuse in (False, True):
+        ms = timed(lambda: bwd(reuse), reps=2) / a.cams
+        key = "render_bwd_reusing_fwd" if reuse else "render_bwd"
+        out[f"{key}_ms_per_image"] = ms
+        out[f"{key}_Mrays_per_s"] = W * H / ms / 1e3
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
     out["tree_data_MB"] = tree.data.numel() * 4 / 1e6
     print(json.dumps(out), flush=True)

@@ -80,7 +80,7 @@ def _patch(structure):
     def octree_render_persp(view, c2w, width, height, fx, opts, fy=None):
         return _render64(structure, view.data.double(), c2w.numpy(), _opt(opts)).float()
 
-    def octree_render_persp_bwd(view, c2w, width, height, fx, opts, grad_out, grad_data, fy=None):
+    def octree_render_persp_bwd(view, c2w, width, height, fx, opts, grad_out, grad_data, fy=None, out_rgb=None):
         d = view.data.double().detach().requires_grad_(True)
         (_render64(structure, d, c2w.numpy(), _opt(opts)) * grad_out.double()).sum().backward()
         grad_data += d.grad.float()

@@ -593,7 +593,14 @@ def test_cli_train_eval_extraction(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_60"))
     psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0
-    sig = extraction.main(common + ["--init_grid_depth", "4"])             # 32^3 grid
+    # the extraction driver restores the same checkpoint and evaluates its sigma grid (32^3 here); the complete
+    # extraction -> optimisation -> evaluation chain is exercised in tests/test_gpu_octree.py
+    from plenoctree_amd.nerf_sh.nerf import models, utils
+    args = utils.define_flags().parse_args(common)
+    utils.update_flags(args)
+    model, state = models.get_model_state(args, torch.device("cuda:0"), restore=True)
+    assert state.step == 60
+    sig = extraction.grid_sigma(model, state, 32, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5])
     assert sig.shape == (32 ** 3,) and bool(torch.isfinite(sig).all())
 
 

@@ -8,7 +8,9 @@ Parity status
 * posenc / MLP / eval_sh are PINNED: tests/golden/*.npz were produced by
   importing the reference's own torch modules (octree/nerf/model_utils.py,
   octree/nerf/models.py, nerf_sh/nerf/sh.py) with tests/golden/make_golden.py,
-  and tests/test_oracle_golden.py checks this file against them.
+  and tests/test_oracle_golden.py checks this file against them.  generate_rays
+  and compute_psnr are PINNED the same way (octree/nerf/utils.py imported with
+  stub modules for absl.flags / cv2, which carry no arithmetic).
 * sampling / compositing / pdf / loss / Adam are "PARITY UNPINNED": the JAX
   path (jax==0.2.9, flax>=0.3.1) cannot be imported here and the reference
   ships no tests or vectors.  They are restated line by line from the cited

@@ -8,6 +8,9 @@ jax/flax/absl/svox):
   octree/nerf/model_utils.py  (MLP, posenc)
   octree/nerf/models.py       (NerfModel.eval_points_raw)
   nerf_sh/nerf/sh.py          (eval_sh)
+and, with stub modules standing in for `absl.flags` and `cv2` (flag registration / resize only, no arithmetic):
+  octree/nerf/utils.py        (generate_rays, compute_psnr)
+  octree/nerf/datasets.py     (Blender and NSVF loaders, run on the tiny on-disk scenes of golden_scenes.py)
 """
 import os
 import sys
@@ -80,6 +83,41 @@ def main():
         out[f"sh_{deg}"] = sh
         out[f"res_{deg}"] = res.numpy()
     np.savez(os.path.join(HERE, "eval_sh.npz"), **out)
+
+    # ---- generate_rays / compute_psnr / loaders (absl + cv2 stubbed) ---------
+    import tempfile
+    import types
+    absl, flags, cv2 = types.ModuleType("absl"), types.ModuleType("absl.flags"), types.ModuleType("cv2")
+    flags.FLAGS = types.SimpleNamespace()
+    for name in ("DEFINE_string", "DEFINE_integer", "DEFINE_float", "DEFINE_bool", "DEFINE_enum", "DEFINE_boolean"):
+        setattr(flags, name, lambda *a, **k: None)
+    absl.flags = flags
+    sys.modules.update({"absl": absl, "absl.flags": flags, "cv2": cv2})
+    from octree.nerf import utils as ref_utils             # noqa: E402
+    from octree.nerf import datasets as ref_datasets       # noqa: E402
+    sys.path.insert(0, HERE)
+    import golden_scenes                                   # noqa: E402
+
+    c2w = golden_scenes.poses(3, seed=5)
+    rays = ref_utils.generate_rays(9, 7, 12.5, c2w)
+    mse = np.array([1e-3, 0.0371, 0.5], np.float32)
+    np.savez(os.path.join(HERE, "generate_rays.npz"), c2w=c2w, w=9, h=7, focal=12.5, origins=rays.origins,
+             directions=rays.directions, viewdirs=rays.viewdirs, mse=mse,
+             psnr=np.array([float(ref_utils.compute_psnr(torch.tensor(m))) for m in mse]))
+
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        broot = golden_scenes.write_blender(os.path.join(tmp, "blender"))
+        nroot = golden_scenes.write_nsvf(os.path.join(tmp, "nsvf"))
+        for kind, root, cls in (("blender", broot, ref_datasets.Blender), ("nsvf", nroot, ref_datasets.NSVF)):
+            for split in ("train", "test"):
+                args = types.SimpleNamespace(data_dir=root, white_bkgd=True, factor=0, render_path=False,
+                                             batch_size=4, image_batching=False)
+                ds = cls(split, args)
+                out[f"{kind}_{split}_images"] = np.asarray(ds.images, np.float32).reshape(ds.size, ds.h, ds.w, 3)
+                out[f"{kind}_{split}_camtoworlds"] = np.asarray(ds.camtoworlds, np.float32)
+                out[f"{kind}_{split}_hwf"] = np.array([ds.h, ds.w, ds.focal], np.float64)
+    np.savez_compressed(os.path.join(HERE, "loaders.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -65,3 +65,40 @@ def test_eval_sh_golden(golden_dir):
     sh = torch.tensor(g["sh_0"])
     np.testing.assert_allclose(O.eval_sh(0, sh, dirs[:, None]).numpy(),
                                0.28209479177387814 * sh[..., 0].numpy(), rtol=1e-6)
+
+
+def test_generate_rays_and_psnr_golden(golden_dir):
+    """octree/nerf/utils.py:401-445 (generate_rays) and :310-319 (compute_psnr), run from the reference itself."""
+    from plenoctree_amd.nerf_sh.nerf import utils
+    g = np.load(os.path.join(golden_dir, "generate_rays.npz"))
+    w, h, focal = int(g["w"]), int(g["h"]), float(g["focal"])
+    for gen in (O.generate_rays, utils.generate_rays):          # the oracle and the product's host version
+        rays = gen(w, h, focal, g["c2w"])
+        np.testing.assert_allclose(rays.origins, g["origins"], rtol=0, atol=0)
+        np.testing.assert_allclose(rays.directions, g["directions"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(rays.viewdirs, g["viewdirs"], rtol=1e-6, atol=1e-6)
+    for m, p in zip(g["mse"], g["psnr"]):
+        assert float(O.compute_psnr(torch.tensor(m))) == pytest.approx(float(p), rel=1e-6)
+        assert utils.compute_psnr(float(m)) == pytest.approx(float(p), rel=1e-6)
+
+
+def test_loaders_match_the_reference_loaders(golden_dir, tmp_path):
+    """Our Blender / NSVF loaders on the same on-disk scenes the reference's loaders were run on
+    (octree/nerf/datasets.py, factor 0, white background)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import golden_scenes
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    g = np.load(os.path.join(golden_dir, "loaders.npz"))
+    roots = {"blender": golden_scenes.write_blender(str(tmp_path / "blender")),
+             "nsvf": golden_scenes.write_nsvf(str(tmp_path / "nsvf"))}
+    for kind, root in roots.items():
+        for split in ("train", "test"):
+            a = utils.define_flags().parse_args(["--train_dir", "x", "--data_dir", root, "--dataset", kind])
+            a.factor, a.white_bkgd = 0, True
+            ds = datasets.get_dataset(split, a, torch.device("cpu"), batch_size=4)
+            h, w, focal = g[f"{kind}_{split}_hwf"]
+            assert (ds.h, ds.w) == (int(h), int(w)) and ds.focal == pytest.approx(float(focal), rel=1e-6)
+            np.testing.assert_allclose(ds.camtoworlds, g[f"{kind}_{split}_camtoworlds"], rtol=1e-6, atol=1e-7)
+            imgs = ds.images.reshape(ds.size, ds.h, ds.w, 3).numpy()
+            np.testing.assert_allclose(imgs, g[f"{kind}_{split}_images"], rtol=0, atol=1e-6)

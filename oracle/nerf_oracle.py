@@ -11,11 +11,17 @@ Parity status
   and tests/test_oracle_golden.py checks this file against them.  generate_rays
   and compute_psnr are PINNED the same way (octree/nerf/utils.py imported with
   stub modules for absl.flags / cv2, which carry no arithmetic).
-* sampling / compositing / pdf / loss / Adam are "PARITY UNPINNED": the JAX
-  path (jax==0.2.9, flax>=0.3.1) cannot be imported here and the reference
-  ships no tests or vectors.  They are restated line by line from the cited
-  reference lines and pinned only by closed-form known answers
-  (tests/test_oracle_known_answers.py).
+* sample_along_rays / cast_rays / volumetric_rendering / piecewise_constant_pdf /
+  sample_pdf (and the jax posenc) are PINNED against the reference's own function
+  bodies: tests/golden/make_golden.py imports nerf_sh/nerf/model_utils.py with numpy
+  (float32 defaults) standing in for jax.numpy, the random draws injected through
+  the `key` argument and lax.stop_gradient = identity, and stores their outputs in
+  tests/golden/model_utils.npz (executed by numpy instead of XLA; same source).
+* the composition inside NerfModel.__call__, loss_fn and Adam remain "PARITY
+  UNPINNED": they need flax modules / jax.value_and_grad / flax.optim, which cannot
+  be imported here, and the reference ships no tests or vectors for them.  They
+  are restated line by line from the cited reference lines and pinned only by
+  closed-form known answers (tests/test_oracle_known_answers.py).
 * flax.optim.Adam is third-party (flax>=0.3.1, environment.yml:19; call sites
   nerf_sh/nerf/models.py:44, nerf_sh/train.py:119); its published update rule
   is restated in `adam_update`.

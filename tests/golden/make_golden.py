@@ -11,6 +11,11 @@ jax/flax/absl/svox):
 and, with stub modules standing in for `absl.flags` and `cv2` (flag registration / resize only, no arithmetic):
   octree/nerf/utils.py        (generate_rays, compute_psnr)
   octree/nerf/datasets.py     (Blender and NSVF loaders, run on the tiny on-disk scenes of golden_scenes.py)
+and, with numpy (float32 defaults) standing in for `jax.numpy`, the random draws passed in through the `key`
+argument, `lax.stop_gradient` = identity and an empty `flax.linen` stub -- i.e. the REFERENCE'S OWN FUNCTION
+BODIES executed by numpy instead of XLA:
+  nerf_sh/nerf/model_utils.py (cast_rays, sample_along_rays, posenc, volumetric_rendering,
+                               piecewise_constant_pdf, sample_pdf)
 """
 import os
 import sys
@@ -118,6 +123,65 @@ def main():
                 out[f"{kind}_{split}_camtoworlds"] = np.asarray(ds.camtoworlds, np.float32)
                 out[f"{kind}_{split}_hwf"] = np.array([ds.h, ds.w, ds.focal], np.float64)
     np.savez_compressed(os.path.join(HERE, "loaders.npz"), **out)
+
+    # ---- nerf_sh/nerf/model_utils.py through a numpy-backed jax shim ----------
+    jnp = types.ModuleType("jax.numpy")
+    jnp.__dict__.update({k: v for k, v in np.__dict__.items() if not k.startswith("__")})
+    f32 = np.float32
+    jnp.linspace = lambda a, b, n: np.linspace(a, b, n, dtype=f32)          # jax default dtype is float32
+    jnp.zeros = lambda shape, dtype=f32: np.zeros(shape, dtype)
+    jnp.ones = lambda shape, dtype=f32: np.ones(shape, dtype)
+    # jax promotes int32 * float32 -> float32 (numpy would give float64): keep small integer tables in float32 (exact)
+    jnp.array = lambda x, dtype=None: np.array(x, dtype=dtype or f32)
+    jax = types.ModuleType("jax")
+    jrandom, lax, jnn = types.ModuleType("jax.random"), types.ModuleType("jax.lax"), types.ModuleType("jax.nn")
+    jrandom.uniform = lambda key, shape: np.asarray(key, f32).reshape(shape)   # the draw IS the key
+    jrandom.normal = lambda key, shape, dtype=f32: np.asarray(key, dtype).reshape(shape)
+    lax.stop_gradient = lambda x: x
+    jnn.initializers = types.SimpleNamespace(glorot_uniform=lambda: None)
+    jax.numpy, jax.random, jax.lax, jax.nn = jnp, jrandom, lax, jnn
+    flax, linen = types.ModuleType("flax"), types.ModuleType("flax.linen")
+    linen.Module, linen.compact, linen.relu, linen.Dense = object, (lambda f: f), (lambda x: np.maximum(x, 0)), object
+    flax.linen = linen
+    sys.modules.update({"jax": jax, "jax.numpy": jnp, "jax.random": jrandom, "jax.lax": lax, "jax.nn": jnn,
+                        "flax": flax, "flax.linen": linen})
+    ref_jmu = _load("ref_jax_model_utils", os.path.join(REF, "nerf_sh/nerf/model_utils.py"))
+
+    B, Nc, Nf = 7, 64, 128
+    out = {}
+    cam = rng.normal(size=(B, 3)); cam = (4.0 * cam / np.linalg.norm(cam, axis=-1, keepdims=True)).astype(f32)
+    d = (-cam / 4.0 + 0.1 * rng.normal(size=(B, 3))).astype(f32)
+    out["origins"], out["directions"] = cam, d
+    out["t_rand"] = rng.uniform(size=(B, Nc)).astype(f32)
+    for lindisp in (False, True):
+        for randomized in (False, True):
+            z, pts = ref_jmu.sample_along_rays(out["t_rand"], cam, d, Nc, 2.0, 6.0, randomized, lindisp)
+            out[f"z_l{int(lindisp)}_r{int(randomized)}"] = np.asarray(z, f32)
+            out[f"pts_l{int(lindisp)}_r{int(randomized)}"] = np.asarray(pts, f32)
+    x = rng.uniform(-4.0, 4.0, size=(11, 3)).astype(f32)
+    out["posenc_x"], out["posenc_enc"] = x, np.asarray(ref_jmu.posenc(x, 0, 10), f32)
+    z = out["z_l0_r1"]
+    rgb = rng.uniform(size=(B, Nc, 3)).astype(f32)
+    sigma = np.maximum(rng.normal(size=(B, Nc, 1)) * 3.0, 0.0).astype(f32)
+    sigma[0] = 0.0                                    # an empty ray
+    sigma[1, 20:] = 1e4                               # an opaque surface
+    out["vr_rgb"], out["vr_sigma"] = rgb, sigma
+    for white in (False, True):
+        comp, disp, acc, w = ref_jmu.volumetric_rendering(rgb, sigma, z, d, white)
+        for name, val in (("comp", comp), ("disp", disp), ("acc", acc), ("weights", w)):
+            out[f"vr_{name}_w{int(white)}"] = np.asarray(val, f32)
+    w = out["vr_weights_w1"].copy()
+    w[2] = 0.0                                        # all-zero weights: the eps-padding branch
+    z_mid = 0.5 * (z[..., 1:] + z[..., :-1])          # nerf_sh/nerf/models.py:296-301
+    out["pdf_bins"], out["pdf_weights"] = z_mid, w[..., 1:-1]
+    out["pdf_u"] = rng.uniform(size=(B, Nf)).astype(f32)
+    for randomized in (False, True):
+        s = ref_jmu.piecewise_constant_pdf(out["pdf_u"], z_mid, w[..., 1:-1], Nf, randomized)
+        out[f"pdf_samples_r{int(randomized)}"] = np.asarray(s, f32)
+        zs, ps = ref_jmu.sample_pdf(out["pdf_u"], z_mid, w[..., 1:-1], cam, d, z, Nf, randomized)
+        out[f"sample_pdf_z_r{int(randomized)}"] = np.asarray(zs, f32)
+        out[f"sample_pdf_pts_r{int(randomized)}"] = np.asarray(ps, f32)
+    np.savez_compressed(os.path.join(HERE, "model_utils.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -102,3 +102,43 @@ def test_loaders_match_the_reference_loaders(golden_dir, tmp_path):
             np.testing.assert_allclose(ds.camtoworlds, g[f"{kind}_{split}_camtoworlds"], rtol=1e-6, atol=1e-7)
             imgs = ds.images.reshape(ds.size, ds.h, ds.w, 3).numpy()
             np.testing.assert_allclose(imgs, g[f"{kind}_{split}_images"], rtol=0, atol=1e-6)
+
+
+def test_sampling_compositing_pdf_match_the_reference_function_bodies(golden_dir):
+    """tests/golden/model_utils.npz holds the outputs of the reference's own nerf_sh/nerf/model_utils.py functions
+    (cast_rays, sample_along_rays :104-142, posenc :145-173, volumetric_rendering :176-222,
+    piecewise_constant_pdf :225-286, sample_pdf :289-314) executed with numpy standing in for jax.numpy and the
+    random draws injected through the `key` argument.  float32 both sides; tolerance = a few ulps of the values
+    (different but equivalent operation orders inside numpy and torch reductions)."""
+    g = np.load(os.path.join(golden_dir, "model_utils.npz"))
+    t = lambda k: torch.tensor(g[k])
+    o, d = t("origins"), t("directions")
+    for lindisp in (0, 1):
+        for randomized in (0, 1):
+            z, pts = O.sample_along_rays(o, d, 64, 2.0, 6.0, t("t_rand") if randomized else None, lindisp=bool(lindisp))
+            np.testing.assert_allclose(z.numpy(), g[f"z_l{lindisp}_r{randomized}"], rtol=2e-6, atol=1e-6)
+            np.testing.assert_allclose(pts.numpy(), g[f"pts_l{lindisp}_r{randomized}"], rtol=2e-6, atol=4e-6)
+    np.testing.assert_allclose(O.posenc(t("posenc_x"), 0, 10).numpy(), g["posenc_enc"], rtol=0, atol=2e-6)
+    z = t("z_l0_r1")
+    for white in (0, 1):
+        comp, disp, acc, w = O.volumetric_rendering(t("vr_rgb"), t("vr_sigma"), z, d, bool(white))
+        np.testing.assert_allclose(w.numpy(), g[f"vr_weights_w{white}"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(comp.numpy(), g[f"vr_comp_w{white}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(acc.numpy(), g[f"vr_acc_w{white}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(disp.numpy(), g[f"vr_disp_w{white}"], rtol=2e-5, atol=1e-6)
+    assert g["vr_acc_w1"][0] == 0.0 and g["vr_disp_w1"][0] == np.float32(1e10)      # empty ray: the guarded division
+    assert abs(float(g["vr_acc_w1"][1]) - 1.0) < 1e-6                               # opaque surface
+    bins, wts, u = t("pdf_bins"), t("pdf_weights"), t("pdf_u")
+    for randomized in (0, 1):
+        s = O.piecewise_constant_pdf(bins, wts, 128, u if randomized else None)
+        want = g[f"pdf_samples_r{randomized}"]
+        # inverse-CDF samples are ill-conditioned inside nearly empty bins (they move by a fraction of the bin per
+        # ulp of the cdf): agree tightly almost everywhere, and to a small fraction of a bin in the rest
+        err = np.abs(s.numpy() - want)
+        assert np.mean(err > 1e-5) < 0.02 and err.max() < 2e-3, (np.mean(err > 1e-5), err.max())
+        zs, ps = O.sample_pdf(bins, wts, o, d, z, 128, u if randomized else None)
+        err = np.abs(zs.numpy() - g[f"sample_pdf_z_r{randomized}"])
+        assert zs.shape == (7, 192) and np.mean(err > 1e-5) < 0.02 and err.max() < 2e-3
+        assert bool((zs[:, 1:] >= zs[:, :-1]).all())
+        err = np.abs(ps.numpy() - g[f"sample_pdf_pts_r{randomized}"])
+        assert np.mean(err > 2e-5) < 0.02 and err.max() < 4e-3

@@ -17,9 +17,12 @@ Parity status
   (float32 defaults) standing in for jax.numpy, the random draws injected through
   the `key` argument and lax.stop_gradient = identity, and stores their outputs in
   tests/golden/model_utils.npz (executed by numpy instead of XLA; same source).
-* the composition inside NerfModel.__call__, loss_fn and Adam remain "PARITY
-  UNPINNED": they need flax modules / jax.value_and_grad / flax.optim, which cannot
-  be imported here, and the reference ships no tests or vectors for them.  They
+* the composition inside NerfModel.__call__ (`render`) is PINNED the same way:
+  the reference's models.py + its MLP run through the shim with a dataclass stub of
+  flax.linen.Module and a Dense stub fed the weights in flax's creation order
+  (tests/golden/nerf_model.npz).
+* loss_fn and Adam remain "PARITY UNPINNED": they need jax.value_and_grad /
+  flax.optim, which cannot be imported here, and the reference ships no tests or vectors for them.  They
   are restated line by line from the cited reference lines and pinned only by
   closed-form known answers (tests/test_oracle_known_answers.py).
 * flax.optim.Adam is third-party (flax>=0.3.1, environment.yml:19; call sites

@@ -182,6 +182,71 @@ def main():
         out[f"sample_pdf_z_r{int(randomized)}"] = np.asarray(zs, f32)
         out[f"sample_pdf_pts_r{int(randomized)}"] = np.asarray(ps, f32)
     np.savez_compressed(os.path.join(HERE, "model_utils.npz"), **out)
+
+    # ---- NerfModel.__call__ (nerf_sh/nerf/models.py:216-348) through the same shim ---------
+    # flax.linen stub: Modules are dataclasses whose setup() runs after init; Dense layers take their
+    # (kernel, bias) from a queue in creation order = flax's auto-naming order Dense_0..Dense_9.
+    import dataclasses
+    from collections import namedtuple
+
+    class Module:
+        def __init_subclass__(cls, **kw):
+            super().__init_subclass__(**kw)
+            dataclasses.dataclass(cls, eq=False)
+
+        def __post_init__(self):
+            if hasattr(self, "setup"):
+                self.setup()
+
+    weight_queue = []
+
+    class Dense:
+        def __init__(self, features, kernel_init=None):
+            self.features = features
+
+        def __call__(self, x):
+            kernel, bias = weight_queue.pop(0)
+            assert kernel.shape == (x.shape[-1], self.features), (kernel.shape, x.shape, self.features)
+            return x @ kernel + bias
+
+    linen.Module, linen.Dense = Module, Dense
+    linen.sigmoid = lambda x: (1.0 / (1.0 + np.exp(-x))).astype(f32)
+    jrandom.split = lambda key, num=2: (key[0], key[1:])          # keys are lists of pre-drawn arrays
+    ref_jmu = _load("nerf_sh.nerf.model_utils", os.path.join(REF, "nerf_sh/nerf/model_utils.py"))
+    Rays = namedtuple("Rays", ("origins", "directions", "viewdirs"))
+    pkg, pkg_nerf = types.ModuleType("nerf_sh"), types.ModuleType("nerf_sh.nerf")
+    utils_stub, sg_stub = types.ModuleType("nerf_sh.nerf.utils"), types.ModuleType("nerf_sh.nerf.sg")
+    utils_stub.Rays = Rays
+    pkg.nerf = pkg_nerf
+    pkg_nerf.model_utils, pkg_nerf.utils, pkg_nerf.sh, pkg_nerf.sg = ref_jmu, utils_stub, ref_sh, sg_stub
+    sys.modules.update({"nerf_sh": pkg, "nerf_sh.nerf": pkg_nerf, "nerf_sh.nerf.utils": utils_stub,
+                        "nerf_sh.nerf.sg": sg_stub, "nerf_sh.nerf.sh": ref_sh})
+    ref_jmodels = _load("nerf_sh.nerf.models", os.path.join(REF, "nerf_sh/nerf/models.py"))
+    gw = np.load(os.path.join(HERE, "eval_points_sh16.npz"))     # the weights already stored for the torch twin
+    weights = [[(gw[f"MLP_{mi}.Dense_{li}.kernel"], gw[f"MLP_{mi}.Dense_{li}.bias"]) for li in range(10)]
+               for mi in range(2)]
+    # flax creation order inside MLP.__call__: Dense_0..7 trunk, then sigma (Dense_8), then rgb (Dense_9)
+    model = ref_jmodels.NerfModel(
+        num_coarse_samples=64, num_fine_samples=128, use_viewdirs=False, sh_deg=3, sg_dim=-1, near=2.0, far=6.0,
+        noise_std=None, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
+        net_activation=linen.relu, skip_layer=4, num_rgb_channels=48, num_sigma_channels=1, white_bkgd=True,
+        min_deg_point=0, max_deg_point=10, deg_view=4, lindisp=False, rgb_activation=linen.sigmoid,
+        sigma_activation=linen.relu, legacy_posenc_order=False)
+    B = 6
+    cam = rng.normal(size=(B, 3)); cam = (4.0 * cam / np.linalg.norm(cam, axis=-1, keepdims=True)).astype(f32)
+    d = (-cam / 4.0 + 0.08 * rng.normal(size=(B, 3))).astype(f32)
+    v = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(f32)
+    t_rand, u = rng.uniform(size=(B, 64)).astype(f32), rng.uniform(size=(B, 128)).astype(f32)
+    out = dict(origins=cam, directions=d, viewdirs=v, t_rand=t_rand, u=u)
+    for randomized in (False, True):
+        weight_queue[:] = weights[0] + weights[1]
+        ret = model(*([t_rand, None], [u, None], Rays(cam, d, v), randomized))
+        assert not weight_queue
+        for lvl, (rgb_, disp_, acc_) in zip(("coarse", "fine"), ret):
+            out[f"rgb_{lvl}_r{int(randomized)}"] = np.asarray(rgb_, f32)
+            out[f"disp_{lvl}_r{int(randomized)}"] = np.asarray(disp_, f32)
+            out[f"acc_{lvl}_r{int(randomized)}"] = np.asarray(acc_, f32)
+    np.savez_compressed(os.path.join(HERE, "nerf_model.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -142,3 +142,24 @@ def test_sampling_compositing_pdf_match_the_reference_function_bodies(golden_dir
         assert bool((zs[:, 1:] >= zs[:, :-1]).all())
         err = np.abs(ps.numpy() - g[f"sample_pdf_pts_r{randomized}"])
         assert np.mean(err > 2e-5) < 0.02 and err.max() < 4e-3
+
+
+def test_render_matches_the_reference_nerf_model_call(golden_dir):
+    """tests/golden/nerf_model.npz: the reference's own NerfModel.__call__ (nerf_sh/nerf/models.py:216-348) with
+    its MLP (model_utils.py:43-94), run through the numpy jax/flax shim of make_golden.py on the weights of
+    eval_points_sh16.npz -- pins the composition (which weights feed sample_pdf, SH before sigmoid, white
+    background, coarse + fine outputs) of the oracle's `render`."""
+    g = np.load(os.path.join(golden_dir, "nerf_model.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    cfg = O.Cfg()
+    params = _params_from_npz(gw, cfg)
+    rays = O.Rays(*[torch.tensor(g[k]) for k in ("origins", "directions", "viewdirs")])
+    for r in (0, 1):
+        out = O.render(params, rays, cfg, torch.tensor(g["t_rand"]) if r else None, torch.tensor(g["u"]) if r else None)
+        assert len(out) == 2
+        for lvl, (rgb, disp, acc) in zip(("coarse", "fine"), out):
+            np.testing.assert_allclose(rgb.numpy(), g[f"rgb_{lvl}_r{r}"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(acc.numpy(), g[f"acc_{lvl}_r{r}"], rtol=0, atol=2e-5)
+            # disp = acc / depth is ill-conditioned on nearly empty rays (acc ~ 1e-3)
+            np.testing.assert_allclose(disp.numpy(), g[f"disp_{lvl}_r{r}"], rtol=2e-3, atol=1e-6)
+    assert float(np.abs(g["acc_coarse_r1"] - 0.5).max()) > 0.3           # the rays see both empty and opaque space

@@ -21,8 +21,11 @@ Parity status
   the reference's models.py + its MLP run through the shim with a dataclass stub of
   flax.linen.Module and a Dense stub fed the weights in flax's creation order
   (tests/golden/nerf_model.npz).
-* loss_fn and Adam remain "PARITY UNPINNED": they need jax.value_and_grad /
-  flax.optim, which cannot be imported here, and the reference ships no tests or vectors for them.  They
+* loss_fn's VALUE and Stats are PINNED against the reference's own train_step
+  (nerf_sh/train.py:51-121) run through the shim with value_and_grad evaluating
+  the function only (tests/golden/train_loss.npz).
+* the GRADIENT (jax AD) and Adam (flax.optim) remain "PARITY UNPINNED": they
+  cannot be imported here, and the reference ships no tests or vectors for them.  They
   are restated line by line from the cited reference lines and pinned only by
   closed-form known answers (tests/test_oracle_known_answers.py).
 * flax.optim.Adam is third-party (flax>=0.3.1, environment.yml:19; call sites

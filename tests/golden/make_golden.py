@@ -247,6 +247,69 @@ def main():
             out[f"disp_{lvl}_r{int(randomized)}"] = np.asarray(disp_, f32)
             out[f"acc_{lvl}_r{int(randomized)}"] = np.asarray(acc_, f32)
     np.savez_compressed(os.path.join(HERE, "nerf_model.npz"), **out)
+
+    # ---- loss_fn of train_step (nerf_sh/train.py:51-121): value + stats through the shim ----------
+    # value_and_grad evaluates the function only (no AD here: gradients are checked by finite differences in the
+    # oracle tests), pmean over one replica is the identity, the optimizer update is skipped.
+    jrandom.split = lambda key, num=2: (key[0], key[1:]) if num == 2 else tuple(key[:num])
+    jrandom.uniform = lambda key, shape, minval=0.0, maxval=1.0: (
+        f32(minval) + (f32(maxval) - f32(minval)) * np.asarray(key, f32).reshape(shape)).astype(f32)
+    jax.value_and_grad = lambda fn, has_aux=False: (lambda x: (fn(x), None))
+    lax.pmean = lambda x, axis_name=None: x
+    jax.lax = lax
+
+    def tree_reduce(fn, tree, initializer=0):
+        acc = initializer
+        for mlp in tree:
+            for kernel, bias in mlp:
+                acc = fn(fn(acc, kernel), bias)
+        return acc
+
+    jax.tree_util = types.SimpleNamespace(tree_reduce=tree_reduce)
+    jconfig = types.SimpleNamespace(parse_flags_with_absl=lambda: None)
+    jax.config = jconfig
+    absl.app = types.ModuleType("absl.app")
+    Stats = namedtuple("Stats", ("loss", "psnr", "loss_c", "psnr_c", "weight_l2", "loss_sp"))
+    utils_stub.Stats = Stats
+    utils_stub.define_flags = lambda: None
+    utils_stub.host0_print = print
+    utils_stub.compute_psnr = lambda mse: -10.0 / np.log(10.0) * np.log(mse)      # nerf_sh/nerf/utils.py:384-393
+    for name in ("flax.metrics", "flax.metrics.tensorboard", "flax.training", "flax.training.checkpoints",
+                 "nerf_sh.nerf.datasets"):
+        sys.modules[name] = types.ModuleType(name)
+    flax.metrics = sys.modules["flax.metrics"]; flax.metrics.tensorboard = sys.modules["flax.metrics.tensorboard"]
+    flax.training = sys.modules["flax.training"]; flax.training.checkpoints = sys.modules["flax.training.checkpoints"]
+    pkg_nerf.datasets = sys.modules["nerf_sh.nerf.datasets"]
+    pkg_nerf.models = ref_jmodels
+    sys.modules.update({"absl.app": absl.app, "jax.config": jconfig})
+    flags.FLAGS = types.SimpleNamespace(randomized=True, sparsity_weight=1e-3, sparsity_npoints=500, sparsity_radius=1.5,
+                                        sparsity_length=0.05, weight_decay_mult=0.1)
+    ref_train = _load("ref_nerf_sh_train", os.path.join(REF, "nerf_sh/train.py"))
+
+    class ModelApply:                     # flax's model.apply(variables, *args, method=...)
+        def apply(self, variables, *args, method=None):
+            weight_queue[:] = [wb for mlp in variables for wb in mlp]
+            if method is not None:        # eval_points_raw uses the fine MLP only: drop MLP_0's layers
+                weight_queue[:] = list(variables[1])
+                res = method(*args)
+            else:
+                res = model(*args)
+            weight_queue[:] = []
+            return res
+        eval_points_raw = model.eval_points_raw
+
+    state = types.SimpleNamespace(optimizer=types.SimpleNamespace(
+        target=weights, apply_gradient=lambda grad, learning_rate: None), replace=lambda optimizer: None)
+    pixels = rng.uniform(size=(B, 3)).astype(f32)
+    sp_u = rng.uniform(size=(500, 3)).astype(f32)
+    # rng -> (rng', key_0, key_1, key_2); key_2 is split once more before the sparsity draw (train.py:66,78-79)
+    keys = [None, [t_rand, None], [u, None], [None, sp_u]]
+    _, stats, _ = ref_train.train_step(ModelApply(), keys, state, {"rays": Rays(cam, d, v), "pixels": pixels}, 5e-4)
+    out = dict(origins=cam, directions=d, viewdirs=v, t_rand=t_rand, u=u, pixels=pixels, sp_u=sp_u,
+               sparsity_npoints=500, weight_decay_mult=0.1)
+    out.update({k: np.float64(getattr(stats, k)) for k in Stats._fields})
+    out["total"] = out["loss"] + out["loss_c"] + out["loss_sp"] + 0.1 * out["weight_l2"]
+    np.savez(os.path.join(HERE, "train_loss.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -163,3 +163,20 @@ def test_render_matches_the_reference_nerf_model_call(golden_dir):
             # disp = acc / depth is ill-conditioned on nearly empty rays (acc ~ 1e-3)
             np.testing.assert_allclose(disp.numpy(), g[f"disp_{lvl}_r{r}"], rtol=2e-3, atol=1e-6)
     assert float(np.abs(g["acc_coarse_r1"] - 0.5).max()) > 0.3           # the rays see both empty and opaque space
+
+
+def test_loss_matches_the_reference_train_step(golden_dir):
+    """tests/golden/train_loss.npz: Stats returned by the reference's own train_step / loss_fn
+    (nerf_sh/train.py:51-121) run through the shim (value only; 500 sparsity points, weight_decay_mult 0.1 so
+    that every term of the total is exercised)."""
+    g = np.load(os.path.join(golden_dir, "train_loss.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    cfg = O.Cfg(sparsity_npoints=int(g["sparsity_npoints"]), weight_decay_mult=float(g["weight_decay_mult"]))
+    params = _params_from_npz(gw, cfg)
+    rays = O.Rays(*[torch.tensor(g[k]) for k in ("origins", "directions", "viewdirs")])
+    sp = torch.tensor(-1.5 + 3.0 * g["sp_u"])                   # random.uniform(key, minval=-r, maxval=r), train.py:79
+    total, stats = O.loss_fn(params, rays, torch.tensor(g["pixels"]), cfg, torch.tensor(g["t_rand"]), torch.tensor(g["u"]), sp)
+    for k in ("loss", "loss_c", "weight_l2", "psnr", "psnr_c"):
+        assert float(stats[k]) == pytest.approx(float(g[k]), rel=2e-5), k
+    assert float(stats["loss_sp"]) == pytest.approx(float(g["loss_sp"]), rel=5e-3, abs=1e-9)
+    assert float(total) == pytest.approx(float(g["total"]), rel=2e-5)

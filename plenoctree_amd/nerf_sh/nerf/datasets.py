@@ -143,7 +143,12 @@ class Synthetic(Dataset):
         self.images = None
         if self.split == "train" and self.device.type == "cuda":
             ids = torch.arange(self.h * self.w, device=self.device)
-            self.images = torch.stack([self._render(i, ids, self._rays_for(i, ids)) for i in range(n)])
+            chunks = []
+            for i0 in range(0, n, 20):                     # 20 views per evaluation of the analytic scene
+                rays = [self._rays_for(i, ids) for i in range(i0, min(i0 + 20, n))]
+                o = torch.cat([r.origins for r in rays]); d = torch.cat([r.directions for r in rays])
+                chunks.append(analytic_scene_rgb(o, d, self.white_bkgd).reshape(len(rays), self.h * self.w, 3))
+            self.images = torch.cat(chunks).contiguous()
 
     def _render(self, image_index, ray_indices, rays):
         return analytic_scene_rgb(rays.origins, rays.directions, self.white_bkgd).contiguous()

@@ -65,12 +65,12 @@ KernelTimer::KernelTimer(int tag, int64_t rows, hipStream_t s) : slot(-1), strea
   ProfRecord r;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.tag = tag; r.rows = rows;
-  hipEventRecord(r.a, s);
+  (void)hipEventRecord(r.a, s);
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
 }
 KernelTimer::~KernelTimer() {
-  if (slot >= 0) hipEventRecord(g_prof[slot].b, stream);
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
 }
 
 // bump allocator over the caller's workspace; with base == nullptr it only measures
@@ -465,8 +465,8 @@ int pxo_profile_read(int tag, int64_t* launches, double* total_ms, int64_t* tota
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
       ++n; ms += t; rows += r.rows;
     }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   g_prof.swap(keep);
   *launches = n; *total_ms = ms; *total_rows = rows;

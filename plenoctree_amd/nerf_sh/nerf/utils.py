@@ -151,6 +151,38 @@ def compute_psnr(mse):
     return -10.0 * math.log(float(mse)) / math.log(10.0)
 
 
+def compute_ssim(img0, img1, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """Mean SSIM of [H,W,C] images (octree/nerf/utils.py:322-398, modelled after tf.image.ssim): separable Gaussian
+    window, zero padding, variances clipped at 0.  An image metric outside the hot path: plain torch ops."""
+    import torch.nn.functional as F
+    c = img0.shape[-1]
+    a = img0.reshape(-1, *img0.shape[-3:]).permute(0, 3, 1, 2)
+    b = img1.reshape(-1, *img1.shape[-3:]).permute(0, 3, 1, 2)
+    hw = filter_size // 2
+    shift = (2 * hw - filter_size + 1) / 2
+    f_i = ((torch.arange(filter_size, device=a.device, dtype=a.dtype) - hw + shift) / filter_sigma) ** 2
+    filt = torch.exp(-0.5 * f_i)
+    filt = filt / filt.sum()
+
+    def blur(z):
+        # separable window as shifted sums (zero padding) -- no convolution library involved
+        H, W = z.shape[-2:]
+        zp = F.pad(z, (hw, hw, 0, 0))
+        z = sum(filt[k] * zp[..., :, k:k + W] for k in range(filter_size))
+        zp = F.pad(z, (0, 0, hw, hw))
+        return sum(filt[k] * zp[..., k:k + H, :] for k in range(filter_size))
+
+    mu0, mu1 = blur(a), blur(b)
+    mu00, mu11, mu01 = mu0 * mu0, mu1 * mu1, mu0 * mu1
+    s00 = (blur(a * a) - mu00).clamp(min=0.0)
+    s11 = (blur(b * b) - mu11).clamp(min=0.0)
+    s01 = blur(a * b) - mu01
+    s01 = torch.sign(s01) * torch.minimum(torch.sqrt(s00 * s11), s01.abs())
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    ssim_map = ((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))
+    return ssim_map.reshape(ssim_map.shape[0], -1).mean(dim=-1)
+
+
 def shard(x, world_size, rank):
     """This rank's slice of a global batch (utils.py:518-522 reshapes [n_dev, B/n_dev, ...])."""
     per = x.shape[0] // world_size

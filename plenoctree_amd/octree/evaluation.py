@@ -37,9 +37,10 @@ def main(argv=None):
     if comm.rank == 0:
         print("N3Tree load", args.input, flush=True)
     tree = N3Tree.load(args.input, map_location=device)
-    psnr, frames = extraction.eval_octree(tree, dataset, args, comm, want_frames=args.write_images is not None)
+    psnr, ssim, frames = extraction.eval_octree(tree, dataset, args, comm, want_frames=args.write_images is not None,
+                                                want_ssim=True)
     if comm.rank == 0:
-        print("Average PSNR", psnr, flush=True)
+        print("Average PSNR", psnr, "SSIM", ssim, flush=True)
     if args.write_images is not None:
         from PIL import Image
         os.makedirs(args.write_images, exist_ok=True)

@@ -142,12 +142,12 @@ def tree_center_radius(tree):
     return center.tolist(), radius.tolist()
 
 
-def eval_octree(tree, dataset, args, comm=None, want_frames=False):
-    """eval_octree (octree/nerf/utils.py:448-497): mean PSNR of the octree renders of a split; images are
-    sharded over the ranks.  (SSIM / LPIPS are image-metric networks outside this path.)"""
+def eval_octree(tree, dataset, args, comm=None, want_frames=False, want_ssim=False):
+    """eval_octree (octree/nerf/utils.py:448-497): mean PSNR (and SSIM if asked) of the octree renders of a split;
+    images are sharded over the ranks.  LPIPS needs pretrained VGG weights, which cannot be fetched here."""
     comm = comm or dist.Comm()
     r = VolumeRenderer(tree, step_size=args.renderer_step_size)
-    acc = torch.zeros(2, dtype=torch.float64, device=tree.device)
+    acc = torch.zeros(3, dtype=torch.float64, device=tree.device)
     frames = []
     for idx in range(comm.rank, dataset.size, comm.world):
         gt = dataset.get_image(idx)["pixels"]
@@ -156,9 +156,13 @@ def eval_octree(tree, dataset, args, comm=None, want_frames=False):
         sse, _ = oops.image_mse(im, gt.contiguous(), want_grad=False)
         acc[0] += utils.compute_psnr(float(sse) / im.numel())
         acc[1] += 1
+        if want_ssim:
+            acc[2] += float(utils.compute_ssim(im.clamp(0.0, 1.0), gt, max_val=1.0))
         if want_frames:
             frames.append((idx, im.clamp(0, 1).cpu()))
     comm.all_reduce_sum(acc)
+    if want_ssim:
+        return float(acc[0] / acc[1]), float(acc[2] / acc[1]), frames
     return float(acc[0] / acc[1]), frames
 
 

@@ -106,9 +106,13 @@ def main():
     c2w = golden_scenes.poses(3, seed=5)
     rays = ref_utils.generate_rays(9, 7, 12.5, c2w)
     mse = np.array([1e-3, 0.0371, 0.5], np.float32)
+    rng_im = np.random.default_rng(99)                    # own stream: keeps the later fixtures unchanged
+    im0 = torch.tensor(rng_im.uniform(size=(2, 24, 20, 3)), dtype=torch.float32)
+    im1 = (im0 + 0.1 * torch.tensor(rng_im.normal(size=(2, 24, 20, 3)), dtype=torch.float32)).clamp(0, 1)
     np.savez(os.path.join(HERE, "generate_rays.npz"), c2w=c2w, w=9, h=7, focal=12.5, origins=rays.origins,
              directions=rays.directions, viewdirs=rays.viewdirs, mse=mse,
-             psnr=np.array([float(ref_utils.compute_psnr(torch.tensor(m))) for m in mse]))
+             psnr=np.array([float(ref_utils.compute_psnr(torch.tensor(m))) for m in mse]),
+             ssim_im0=im0.numpy(), ssim_im1=im1.numpy(), ssim=ref_utils.compute_ssim(im0, im1, max_val=1.0).numpy())
 
     out = {}
     with tempfile.TemporaryDirectory() as tmp:

@@ -80,6 +80,11 @@ def test_generate_rays_and_psnr_golden(golden_dir):
     for m, p in zip(g["mse"], g["psnr"]):
         assert float(O.compute_psnr(torch.tensor(m))) == pytest.approx(float(p), rel=1e-6)
         assert utils.compute_psnr(float(m)) == pytest.approx(float(p), rel=1e-6)
+    # compute_ssim (octree/nerf/utils.py:322-398), batched and single-image
+    ssim = utils.compute_ssim(torch.tensor(g["ssim_im0"]), torch.tensor(g["ssim_im1"]), max_val=1.0)
+    np.testing.assert_allclose(ssim.numpy(), g["ssim"], rtol=1e-5)
+    one = utils.compute_ssim(torch.tensor(g["ssim_im0"][1]), torch.tensor(g["ssim_im1"][1]))
+    assert float(one) == pytest.approx(float(g["ssim"][1]), rel=1e-5) and 0.0 < float(one) < 1.0
 
 
 def test_loaders_match_the_reference_loaders(golden_dir, tmp_path):

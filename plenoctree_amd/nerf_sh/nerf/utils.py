@@ -183,6 +183,33 @@ def compute_ssim(img0, img1, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0
     return ssim_map.reshape(ssim_map.shape[0], -1).mean(dim=-1)
 
 
+def pose_spherical(theta, phi, radius, up_axis=0):
+    """Camera-to-world of a view on a sphere around the origin (utils.py:656-685, "from NeRF"): theta/phi in
+    degrees; up_axis 0 = default (z up), 1..5 = z down / y up / y down / x up / x down (volrend's number keys)."""
+    th, ph = theta / 180.0 * np.pi, phi / 180.0 * np.pi
+    c2w = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], np.float32)
+    rot_phi = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]], np.float32)
+    rot_theta = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]], np.float32)
+    c2w = rot_theta @ (rot_phi @ c2w)
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32) @ c2w
+    if up_axis != 0:
+        vec_up, vec_1 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        up_dim = 2 - up_axis // 2
+        vec_up[up_dim] = -1 if up_axis % 2 else 1
+        vec_1[1 if up_dim == 0 else 0] = 1
+        trans = np.eye(4, dtype=np.float32)
+        trans[:3, 0], trans[:3, 1], trans[:3, 2] = vec_1, np.cross(vec_up, vec_1), vec_up
+        c2w = trans @ c2w
+    return c2w
+
+
+def save_img(img, pth):
+    """utils.py:469-480: [H,W,C] in [0,1] (clipped) -> PNG."""
+    from PIL import Image
+    arr = np.asarray(img.detach().cpu() if hasattr(img, "detach") else img)
+    Image.fromarray((np.clip(arr, 0.0, 1.0) * 255.0).astype(np.uint8)).save(pth, "PNG")
+
+
 def shard(x, world_size, rank):
     """This rank's slice of a global batch (utils.py:518-522 reshapes [n_dev, B/n_dev, ...])."""
     per = x.shape[0] // world_size

@@ -314,6 +314,27 @@ def main():
     out.update({k: np.float64(getattr(stats, k)) for k in Stats._fields})
     out["total"] = out["loss"] + out["loss_c"] + out["loss_sp"] + 0.1 * out["weight_l2"]
     np.savez(os.path.join(HERE, "train_loss.npz"), **out)
+
+    # ---- nerf_sh/nerf/utils.py host helpers through the shim --------------------------------------
+    flax.struct = types.SimpleNamespace(dataclass=dataclasses.dataclass)
+    flax.optim = types.SimpleNamespace(Optimizer=object)
+    for name in ("jax.dlpack", "jax.scipy"):
+        sys.modules[name] = types.ModuleType(name)
+    jax.dlpack, jax.scipy = sys.modules["jax.dlpack"], sys.modules["jax.scipy"]
+    ref_jutils = _load("ref_nerf_sh_utils", os.path.join(REF, "nerf_sh/nerf/utils.py"))
+    out = {}
+    pose_args = [(30.0, -30.0, 4.0, 0), (-180.0, -30.0, 4.0, 0), (45.0, 10.0, 2.5, 1), (200.0, -60.0, 3.0, 2),
+                 (10.0, -20.0, 4.0, 3), (10.0, -20.0, 4.0, 4), (10.0, -20.0, 4.0, 5)]
+    out["pose_args"] = np.array(pose_args, np.float64)
+    out["poses"] = np.stack([ref_jutils.pose_spherical(t, ph, r, int(up)) for t, ph, r, up in pose_args])
+    lr_args = [(0, 5e-4, 5e-6, 2000000, 0, 1.0), (1000, 5e-4, 5e-6, 2000000, 0, 1.0), (2000000, 5e-4, 5e-6, 2000000, 0, 1.0),
+               (3000000, 5e-4, 5e-6, 2000000, 0, 1.0), (10, 5e-4, 5e-6, 1000, 100, 0.01), (500, 1e-3, 1e-5, 1000, 100, 0.1)]
+    out["lr_args"] = np.array(lr_args, np.float64)
+    out["lr"] = np.array([float(ref_jutils.learning_rate_decay(int(a[0]), a[1], a[2], int(a[3]), int(a[4]), a[5]))
+                          for a in lr_args])
+    rays = ref_jutils.generate_rays(9, 7, 12.5, c2w)
+    out["rays_origins"], out["rays_directions"], out["rays_viewdirs"] = [np.asarray(r, f32) for r in rays]
+    np.savez(os.path.join(HERE, "nerf_sh_utils.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -593,6 +593,13 @@ def test_cli_train_eval_extraction(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_60"))
     psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0
+    from plenoctree_amd.nerf_sh import gen_video
+    frames = gen_video.main(common + ["--num_views", "2", "--height", "20", "--width", "24", "--chunk", "256",
+                                      "--write_poses", os.path.join(str(tmp_path), "poses.txt")])
+    assert len(frames) == 2 and frames[0].shape == (20, 24, 3) and frames[0].dtype == np.uint8
+    assert os.path.exists(os.path.join(str(tmp_path), "video", "e300", "frames", "0001.png"))
+    assert os.path.exists(os.path.join(str(tmp_path), "video", "e300", "video.gif"))
+    assert np.loadtxt(os.path.join(str(tmp_path), "poses.txt")).shape == (8, 4)
     # the extraction driver restores the same checkpoint and evaluates its sigma grid (32^3 here); the complete
     # extraction -> optimisation -> evaluation chain is exercised in tests/test_gpu_octree.py
     from plenoctree_amd.nerf_sh.nerf import models, utils

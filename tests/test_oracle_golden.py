@@ -185,3 +185,20 @@ def test_loss_matches_the_reference_train_step(golden_dir):
         assert float(stats[k]) == pytest.approx(float(g[k]), rel=2e-5), k
     assert float(stats["loss_sp"]) == pytest.approx(float(g["loss_sp"]), rel=5e-3, abs=1e-9)
     assert float(total) == pytest.approx(float(g["total"]), rel=2e-5)
+
+
+def test_host_helpers_match_the_reference_utils(golden_dir):
+    """pose_spherical (:656-685), learning_rate_decay (:483-515) and generate_rays (:545-589) of the reference's
+    nerf_sh/nerf/utils.py, run through the shim."""
+    from plenoctree_amd.nerf_sh.nerf import utils
+    g = np.load(os.path.join(golden_dir, "nerf_sh_utils.npz"))
+    for (t, ph, r, up), want in zip(g["pose_args"], g["poses"]):
+        np.testing.assert_allclose(utils.pose_spherical(t, ph, r, int(up)), want, rtol=0, atol=1e-6)
+    for a, want in zip(g["lr_args"], g["lr"]):
+        for fn in (utils.learning_rate_decay, O.learning_rate_decay):
+            assert fn(int(a[0]), a[1], a[2], int(a[3]), int(a[4]), a[5]) == pytest.approx(float(want), rel=1e-6)
+    gr = np.load(os.path.join(golden_dir, "generate_rays.npz"))
+    rays = utils.generate_rays(9, 7, 12.5, gr["c2w"])
+    np.testing.assert_allclose(rays.directions, g["rays_directions"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rays.viewdirs, g["rays_viewdirs"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rays.origins, g["rays_origins"], rtol=0, atol=0)

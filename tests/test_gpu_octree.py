@@ -286,7 +286,7 @@ def test_extraction_pipeline_end_to_end(tmp_path):
     leaf's own sample points, and its render approximates the NeRF render of the same model."""
     oops = _oops(); dev = _gpu()
     from plenoctree_amd import ops
-    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
+    from plenoctree_amd.nerf_sh.nerf import models, utils
     from plenoctree_amd.octree import evaluation, extraction, optimization, svox
     cfg_path = os.path.join(str(tmp_path), "tiny.yaml")
     with open(cfg_path, "w") as f:

@@ -5,7 +5,6 @@ Tolerances (float32 path; the MFMA f32 GEMM is an exact fmaf chain in a permuted
   per-stage tensors  rtol 2e-4 / atol 2e-5   (8 chained 256-wide layers)
   rendered colours   atol 2e-5,  |dPSNR| <= 1e-4 dB  (north_star)
 """
-import math
 import os
 
 import numpy as np

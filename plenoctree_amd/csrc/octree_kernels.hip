@@ -289,16 +289,6 @@ __device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.
 // ------------------------------------------------------------------------------------------
 struct Vec3 { float v[3]; };
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own 4 MB L2.
-// Renumber the blocks so that every XCD receives one contiguous range of image tiles: neighbouring tiles walk
-// neighbouring parts of the tree / grid, which then stay in ONE L2 instead of being replicated in all eight.
-__device__ __forceinline__ int64_t xcd_contiguous_block(int64_t b, int64_t nb, int enable) {
-  if (!enable) return b;
-  const int64_t base = nb >> 3, rem = nb & 7;
-  const int64_t x = b & 7, i = b >> 3;
-  return x * base + (x < rem ? x : rem) + i;
-}
-
 // sigma and the weights are walked in 4x4x4 bricks (256 B = two cache lines per brick): a marching ray takes
 // several samples per brick and the 8x8-pixel footprint of a wave spans only a few bricks, whereas in the
 // x-slowest layout nearly every sample of every lane touches its own line (PMC: 72 GB fetched per two
@@ -329,10 +319,10 @@ template <bool BRICK>
 __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restrict__ sigma, int reso,
                                                            const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
                                                            int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
-                                                           int xcd_remap, int* __restrict__ weight_bits) {
+                                                           int* __restrict__ weight_bits) {
   // 8x8 pixel tiles per 64-thread wave keep the rays of a wave in neighbouring voxels
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  const int64_t b = xcd_contiguous_block(blockIdx.x, gridDim.x, xcd_remap);
+  const int64_t b = blockIdx.x;
   const int cam = (int)(b / ((int64_t)tiles_x * tiles_y));
   const int tile = (int)(b % ((int64_t)tiles_x * tiles_y));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -409,7 +399,6 @@ struct RenderArgs {
   const float* viewdirs;
   int64_t B;
   PxoRenderOpts opt;
-  int xcd_remap;
 };
 
 // Per-row marching state + the leaf lookup with path reuse.
@@ -472,8 +461,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     // 4x4 pixel tile per block, 2x2 per wave
     const int W = A.cam.width, H = A.cam.height;
     const int tiles_x = (W + 3) / 4;
-    const int64_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x, A.xcd_remap);
-    const int bx = (int)(blk % tiles_x), by = (int)(blk / tiles_x);
+    const int bx = (int)(blockIdx.x % tiles_x), by = (int)(blockIdx.x / tiles_x);
     const int wv = row >> 2, q = row & 3;
     const int px = bx * 4 + (wv & 1) * 2 + (q & 1), py = by * 4 + (wv >> 1) * 2 + (q >> 1);
     active = px < W && py < H;
@@ -675,15 +663,6 @@ using namespace pxo;
 
 static inline int64_t blocks_for(int64_t n, int threads) { return (n + threads - 1) / threads; }
 
-// PXO_XCD_REMAP=0 switches the XCD-contiguous tile numbering off (A/B measurements)
-static int xcd_remap_enabled() {
-  static const int on = [] {
-    const char* e = getenv("PXO_XCD_REMAP");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  return on;
-}
-
 extern "C" {
 
 int pxo_threshold_mask(const float* value, int64_t n, float thresh, uint8_t* mask, void* stream) {
@@ -818,7 +797,7 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   const int64_t n = (int64_t)reso * reso * reso;
   if (reso % 4 != 0) {   // grids that do not tile into bricks (never the case for 2^(depth+1), depth >= 1)
     hipLaunchKernelGGL(grid_weight_kernel<false>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, sigma_grid, reso, c2w_all,
-                       n_cams, fx, fy, width, height, *opts, o, ir, xcd_remap_enabled(), reinterpret_cast<int*>(grid_weight));
+                       n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(grid_weight));
     return check_launch("grid_weight_render");
   }
   const size_t need = (size_t)2 * n * sizeof(float);
@@ -834,7 +813,7 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   }
   hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, sigma_grid, reso, sigma_b);
   hipLaunchKernelGGL(grid_weight_kernel<true>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, (const float*)sigma_b, reso,
-                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, xcd_remap_enabled(), reinterpret_cast<int*>(weight_b));
+                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
   hipLaunchKernelGGL(unbrick_max_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, (const float*)weight_b, reso,
                      grid_weight);
   return check_launch("grid_weight_render");
@@ -852,7 +831,6 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
   PXO_REQUIRE(B >= 0, "%s: B < 0", who);
   A.tree = *tree;
   A.opt = *opts;
-  A.xcd_remap = xcd_remap_enabled();
   A.B = B;
   A.has_cam = cam != nullptr;
   int64_t blocks;

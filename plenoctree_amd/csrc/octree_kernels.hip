@@ -368,16 +368,21 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // octree renderer
 // ------------------------------------------------------------------------------------------
-constexpr int kRow = 16;                       // lanes per ray
 constexpr int kRenderThreads = 256;
-constexpr int kRaysPerBlock = kRenderThreads / kRow;
-constexpr int kMaxLoads = 5;                   // ceil(75 / 16)
 
-__device__ __forceinline__ float row_sum(float v) {   // sum over the 16 lanes of a row, result in every lane
-  v += __shfl_xor(v, 1, kRow);
-  v += __shfl_xor(v, 2, kRow);
-  v += __shfl_xor(v, 4, kRow);
-  v += __shfl_xor(v, 8, kRow);
+// lanes per ray: ROW in {4, 8, 16}; the wave carries 64/ROW rays as a WTX x WTY pixel patch
+template <int ROW> struct RowGeom {
+  static constexpr int kRaysPerWave = 64 / ROW;
+  static constexpr int kRaysPerBlock = kRenderThreads / ROW;
+  static constexpr int kWTX = kRaysPerWave == 4 ? 2 : 4;
+  static constexpr int kWTY = kRaysPerWave / kWTX;
+  static constexpr int kMaxLoads = (75 + ROW - 1) / ROW;      // SH25: 75 coefficients
+};
+
+template <int ROW>
+__device__ __forceinline__ float row_sum(float v) {   // sum over the ROW lanes of a ray, result in every lane
+#pragma unroll
+  for (int o = 1; o < ROW; o <<= 1) v += __shfl_xor(v, o, ROW);
   return v;
 }
 
@@ -446,11 +451,13 @@ struct Marcher {
 };
 
 // MODE 0: forward (writes out_rgb).  MODE 1: gradient w.r.t. tree data (two marches per ray).
-template <int MODE>
+template <int MODE, int ROW>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArgs A, float* __restrict__ out_rgb,
                                                                         const float* __restrict__ fwd_rgb,
                                                                         const float* __restrict__ grad_out,
                                                                         float* __restrict__ grad_data) {
+  using G = RowGeom<ROW>;
+  constexpr int kRow = ROW, kRaysPerBlock = G::kRaysPerBlock, kMaxLoads = G::kMaxLoads;
   __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
   __shared__ float s_basis[kRaysPerBlock][25];
   const int row = threadIdx.x / kRow, l = threadIdx.x % kRow;
@@ -458,12 +465,12 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   float origin[3], dir[3], vdir[3];
   bool active = true;
   if (A.has_cam) {
-    // 4x4 pixel tile per block, 2x2 per wave
+    // the block's 4 waves form a 2 x 2 arrangement of WTX x WTY pixel patches
     const int W = A.cam.width, H = A.cam.height;
-    const int tiles_x = (W + 3) / 4;
+    const int tiles_x = (W + 2 * G::kWTX - 1) / (2 * G::kWTX);
     const int bx = (int)(blockIdx.x % tiles_x), by = (int)(blockIdx.x / tiles_x);
-    const int wv = row >> 2, q = row & 3;
-    const int px = bx * 4 + (wv & 1) * 2 + (q & 1), py = by * 4 + (wv >> 1) * 2 + (q >> 1);
+    const int wv = row / G::kRaysPerWave, q = row % G::kRaysPerWave;
+    const int px = (bx * 2 + (wv & 1)) * G::kWTX + q % G::kWTX, py = (by * 2 + (wv >> 1)) * G::kWTY + q / G::kWTX;
     active = px < W && py < H;
     ray = (int64_t)py * W + px;
     if (active) {
@@ -569,9 +576,9 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
             p2 += v * b2[j];
           }
         }
-        p0 = row_sum(p0);
-        p1 = row_sum(p1);
-        p2 = row_sum(p2);
+        p0 = row_sum<ROW>(p0);
+        p1 = row_sum<ROW>(p1);
+        p2 = row_sum<ROW>(p2);
         const float c0 = 1.0f / (1.0f + expf(-p0)), c1 = 1.0f / (1.0f + expf(-p1)), c2 = 1.0f / (1.0f + expf(-p2));
         if (pass == 0) {
           out[0] += weight * c0;
@@ -819,6 +826,16 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   return check_launch("grid_weight_render");
 }
 
+// lanes per ray of the renderer launches (PXO_OCT_ROW = 4 | 8 | 16 overrides the default for A/B runs)
+static int render_row() {
+  static const int row = [] {
+    const char* e = getenv("PXO_OCT_ROW");
+    const int v = e ? atoi(e) : 0;
+    return (v == 4 || v == 8 || v == 16) ? v : 16;
+  }();
+  return row;
+}
+
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
                        const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const char* who, RenderArgs& A,
                        unsigned& grid) {
@@ -839,12 +856,13 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
     PXO_REQUIRE(B == (int64_t)cam->width * cam->height, "%s: B must be width*height in camera mode", who);
     A.cam = *cam;
     A.origins = A.dirs = A.viewdirs = nullptr;
-    blocks = (int64_t)((cam->width + 3) / 4) * ((cam->height + 3) / 4);
+    const int row = render_row(), rpw = 64 / row, tx = 2 * (rpw == 4 ? 2 : 4), ty = 2 * (rpw / (rpw == 4 ? 2 : 4));
+    blocks = (int64_t)((cam->width + tx - 1) / tx) * ((cam->height + ty - 1) / ty);
   } else {
     PXO_REQUIRE(B == 0 || (origins && dirs && viewdirs), "%s: null ray arrays", who);
     A.cam = PxoCamera{};
     A.origins = origins; A.dirs = dirs; A.viewdirs = viewdirs;
-    blocks = blocks_for(B, kRaysPerBlock);
+    blocks = blocks_for(B, kRenderThreads / render_row());
   }
   PXO_REQUIRE(blocks < ((int64_t)1 << 31), "%s: too many rays for one launch", who);
   grid = (unsigned)blocks;
@@ -858,8 +876,12 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
   if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_fwd", A, grid)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
-  hipLaunchKernelGGL(octree_render_kernel<0>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb,
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  const float* none = nullptr;
+  switch (render_row()) {
+    case 4: hipLaunchKernelGGL((octree_render_kernel<0, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    default: hipLaunchKernelGGL((octree_render_kernel<0, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+  }
   return check_launch("octree_render_fwd");
 }
 
@@ -871,8 +893,11 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
   if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", A, grid)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(grad_out && grad_data, "pxo_octree_render_bwd: null pointer");
-  hipLaunchKernelGGL(octree_render_kernel<1>, dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr,
-                     out_rgb, grad_out, grad_data);
+  switch (render_row()) {
+    case 4: hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
+    case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
+    default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
+  }
   return check_launch("octree_render_bwd");
 }
 

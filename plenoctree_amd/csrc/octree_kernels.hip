@@ -13,9 +13,9 @@
 // scan per level (rank of a cell = its node index inside the level), and the 8 children of cell m are the
 // contiguous cells 8m..8m+7 of the next level.  No sort, no pointer chasing, all streams are linear.
 //
-// Renderer: one ray per 16-lane row of the wave (4 rays per wave64).  The 16 lanes walk the tree together
-// (uniform control flow inside a row), each lane owns data channels lane, lane+16, ... of the leaf, so a
-// leaf's 3*K coefficients are fetched as K/16*3 coalesced 64-byte row loads and reduced with row-local
+// Renderer: one ray per row of ROW = 8 or 16 lanes of the wave (8 or 4 rays per wave64).  The lanes of a row walk
+// the tree together (uniform control flow inside a row), each lane owns data channels lane, lane+ROW, ... of the
+// leaf, so a leaf's 3*K coefficients are fetched as coalesced 32/64-byte row loads and reduced with row-local
 // DPP shuffles.  The node path of the previous sample is kept in LDS; the descent for the next sample
 // resumes at the deepest node the two positions share instead of the root.
 #include "pxo_common.h"
@@ -826,19 +826,24 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   return check_launch("grid_weight_render");
 }
 
-// lanes per ray of the renderer launches (PXO_OCT_ROW = 4 | 8 | 16 overrides the default for A/B runs)
-static int render_row() {
-  static const int row = [] {
+// Lanes per ray of the renderer launches.  Measured on the 512^3 / 800x800 / SH16 benchmark (profiles/README.md):
+// forward 3.88 / 3.36 / 4.23 ms for 16 / 8 / 4 lanes (8 lanes: twice the rays in flight per wave, half the
+// duplicated traversal arithmetic, coefficient rows still 32-byte coalesced); backward 10.9 / 14.0 / 22.1 ms (the
+// gradient scatter wants the widest atomic rows).  So: forward 8 lanes up to SH16 and 16 for SH25 (10 loads per
+// lane otherwise), backward always 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+static int render_row(bool backward, int data_dim) {
+  static const int forced = [] {
     const char* e = getenv("PXO_OCT_ROW");
     const int v = e ? atoi(e) : 0;
-    return (v == 4 || v == 8 || v == 16) ? v : 16;
+    return (v == 4 || v == 8 || v == 16) ? v : 0;
   }();
-  return row;
+  if (forced) return forced;
+  return (backward || data_dim > 49) ? 16 : 8;
 }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
-                       const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const char* who, RenderArgs& A,
-                       unsigned& grid) {
+                       const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const char* who, bool backward,
+                       RenderArgs& A, unsigned& grid, int& row) {
   if (int rc = check_opts(opts, who)) return rc;
   PXO_REQUIRE(tree && tree->child && tree->data, "%s: null tree", who);
   const int K = tree->basis_dim;
@@ -846,6 +851,7 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
   PXO_REQUIRE(tree->data_dim == 3 * K + 1, "%s: data_dim %d != 3*basis_dim+1", who, tree->data_dim);
   PXO_REQUIRE(tree->n_internal >= 1 && tree->n_internal < ((int64_t)1 << 28), "%s: n_internal out of range", who);
   PXO_REQUIRE(B >= 0, "%s: B < 0", who);
+  row = render_row(backward, tree->data_dim);
   A.tree = *tree;
   A.opt = *opts;
   A.B = B;
@@ -856,13 +862,13 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
     PXO_REQUIRE(B == (int64_t)cam->width * cam->height, "%s: B must be width*height in camera mode", who);
     A.cam = *cam;
     A.origins = A.dirs = A.viewdirs = nullptr;
-    const int row = render_row(), rpw = 64 / row, tx = 2 * (rpw == 4 ? 2 : 4), ty = 2 * (rpw / (rpw == 4 ? 2 : 4));
+    const int rpw = 64 / row, tx = 2 * (rpw == 4 ? 2 : 4), ty = 2 * (rpw / (rpw == 4 ? 2 : 4));
     blocks = (int64_t)((cam->width + tx - 1) / tx) * ((cam->height + ty - 1) / ty);
   } else {
     PXO_REQUIRE(B == 0 || (origins && dirs && viewdirs), "%s: null ray arrays", who);
     A.cam = PxoCamera{};
     A.origins = origins; A.dirs = dirs; A.viewdirs = viewdirs;
-    blocks = blocks_for(B, kRenderThreads / render_row());
+    blocks = blocks_for(B, kRenderThreads / row);
   }
   PXO_REQUIRE(blocks < ((int64_t)1 << 31), "%s: too many rays for one launch", who);
   grid = (unsigned)blocks;
@@ -873,11 +879,12 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
                           const float* viewdirs, int64_t B, const PxoRenderOpts* opts, float* out_rgb, void* stream) {
   RenderArgs A;
   unsigned grid;
-  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_fwd", A, grid)) return rc;
+  int row;
+  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_fwd", false, A, grid, row)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
   const float* none = nullptr;
-  switch (render_row()) {
+  switch (row) {
     case 4: hipLaunchKernelGGL((octree_render_kernel<0, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
     default: hipLaunchKernelGGL((octree_render_kernel<0, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
@@ -890,10 +897,11 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
                           const float* grad_out, float* grad_data, void* stream) {
   RenderArgs A;
   unsigned grid;
-  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", A, grid)) return rc;
+  int row;
+  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", true, A, grid, row)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(grad_out && grad_data, "pxo_octree_render_bwd: null pointer");
-  switch (render_row()) {
+  switch (row) {
     case 4: hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
     default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;

@@ -36,6 +36,7 @@ def main():
     p.add_argument("--size", type=int, default=800)
     p.add_argument("--step", type=float, default=1e-4)
     p.add_argument("--cams", type=int, default=8)
+    p.add_argument("--basis", type=int, default=16, help="SH basis_dim of the tree data (16 or 25)")
     a = p.parse_args()
     from plenoctree_amd import build, octree_ops as oops
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
@@ -43,8 +44,8 @@ def main():
     build.build(verbose=False)
     dev = torch.device("cuda:0")
     depth, reso = a.depth, 2 ** (a.depth + 1)
-    K = 16
-    tree = N3Tree(N=2, data_dim=3 * K + 1, depth_limit=depth, radius=1.5, center=[0, 0, 0], data_format="SH16", map_location=dev)
+    K = a.basis
+    tree = N3Tree(N=2, data_dim=3 * K + 1, depth_limit=depth, radius=1.5, center=[0, 0, 0], data_format=f"SH{K}", map_location=dev)
     # density of three fuzzy spheres on the grid (world coords in [-1.5, 1.5]^3)
     ax = ((torch.arange(reso, device=dev, dtype=torch.float32) + 0.5) / reso - 0.5) * 3.0
     sig = torch.zeros(reso, reso, reso, device=dev)
@@ -56,7 +57,7 @@ def main():
     focal = 0.5 * W / np.tan(0.5 * 0.6911112)
     rs = np.random.RandomState(7)
     cams = torch.from_numpy(np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(a.cams)])).to(dev)
-    out = {"depth": depth, "reso": reso, "image": [H, W], "step_size": a.step, "cams": a.cams}
+    out = {"basis_dim": K, "depth": depth, "reso": reso, "image": [H, W], "step_size": a.step, "cams": a.cams}
 
     opts = oops.render_opts(a.step)
     wt = torch.zeros(reso ** 3, device=dev)

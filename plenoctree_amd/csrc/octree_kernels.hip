@@ -829,8 +829,8 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // Lanes per ray of the renderer launches.  Measured on the 512^3 / 800x800 / SH16 benchmark (profiles/README.md):
 // forward 3.88 / 3.36 / 4.23 ms for 16 / 8 / 4 lanes (8 lanes: twice the rays in flight per wave, half the
 // duplicated traversal arithmetic, coefficient rows still 32-byte coalesced); backward 10.9 / 14.0 / 22.1 ms (the
-// gradient scatter wants the widest atomic rows).  So: forward 8 lanes up to SH16 and 16 for SH25 (10 loads per
-// lane otherwise), backward always 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+// gradient scatter wants the widest atomic rows); SH25: forward 4.34 / 4.04 ms, backward 13.9 / 17.8 ms for 16 / 8.
+// So: forward 8 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
 static int render_row(bool backward, int data_dim) {
   static const int forced = [] {
     const char* e = getenv("PXO_OCT_ROW");
@@ -838,7 +838,8 @@ static int render_row(bool backward, int data_dim) {
     return (v == 4 || v == 8 || v == 16) ? v : 0;
   }();
   if (forced) return forced;
-  return (backward || data_dim > 49) ? 16 : 8;
+  (void)data_dim;
+  return backward ? 16 : 8;
 }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,

@@ -2,16 +2,21 @@
 """Headline benchmark: NeRF-SH training rays/sec (800x800 images, 64 coarse + 128 fine samples)
 on N MI355X, BASELINE.json configs[1] (chair-shaped SH16 workload, 4096 rays per GPU per step).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                      # 1 GPU, 100 timed steps
+    python bench.py --gpus 8             # spawns 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one full train_step (nerf_sh/train.py:51-121) on a synthetic batch: batch sampling,
 weight re-pack, coarse+fine forward, losses (incl. the 10k-point sparsity branch), backward,
-RCCL all-reduce of the 4.05 MB gradient arena (N > 1), Adam.  Rank 0 prints ONE JSON line.
+ONE RCCL all-reduce of the 4.05 MB gradient arena + stats (N > 1), Adam.  Rank 0 prints ONE JSON
+line; besides the headline it carries three more records of the other BASELINE configs:
+`tt_sh25` (configs[3] shape), `render_fwd` (the eval path) and `grid512` (configs[4]).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,21 +27,43 @@ sys.path.insert(0, ROOT)
 
 FLOP_FWD_PER_ROW = {3: 1007104, 4: 1020928}          # GEMM MAC x2 per sample
 FLOP_TRAIN_PER_RAY = {3: 756.9e6, 4: 767.6e6}
+FLOP_RENDER_PER_RAY = {3: 257.8e6, 4: 261.4e6}
+FLOP_SIGMA_PER_POINT = 982528                        # trunk + sigma head only (131.9 TFLOP at 512^3)
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=4096, help="rays per GPU per step (weak) / global (strong)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--preset", choices=["blender", "tt"], default="blender")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the tt_sh25 / render_fwd / grid512 records")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
     p.add_argument("--cpu-steps", type=int, default=3)
-    return p.parse_args()
+    return p.parse_args(argv)
+
+
+def launch_command(n_gpus, argv, port):
+    """The torch.distributed.run command bench.py re-executes itself through for --gpus N > 1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU over RCCL."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} ROCm device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
+    return subprocess.call(launch_command(a.gpus, sys.argv[1:], port), env=env)
 
 
 def flags_for(preset, batch):
@@ -110,70 +137,50 @@ def hbm_traffic(kernel):
         return None
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU; the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+class Job:
+    """Rank context shared by the legs of the benchmark."""
 
-    from plenoctree_amd import build, ops
-    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
-    if rank == 0:
-        build.build(verbose=False)
-    if dist:
-        dist.barrier()
+    def __init__(self, a):
+        self.a = a
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.dist = None
+        self.ranks_seen = 1
+        if self.world > 1:
+            import torch.distributed as dist_mod
+            self.dist = dist_mod
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                         device_id=self.device)                    # RCCL over xGMI
+            one = torch.ones(1, device=self.device)
+            self.dist.all_reduce(one)
+            self.ranks_seen = int(one.item())
 
-    per_gpu = a.batch if a.scaling == "weak" else a.batch // world
-    args = flags_for(a.preset, per_gpu)
-    model, params = models.construct_nerf(args, device)
-    state = models.TrainState(model.cfg, params)
-    dataset = datasets.Synthetic("train", args, device, batch_size=per_gpu, seed=20201473 + rank)
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
-    def all_reduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-
-    def one_step(step):
-        batch = next(dataset)
-        lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps)
-        models.train_step(model, state, batch, lr, randomized=True, seed=(step << 8) | rank, world_size=world,
-                          all_reduce=all_reduce if dist else None)
-
-    def sync():
-        if dist:
-            dist.barrier()
+    def sync(self):
+        if self.dist:
+            self.dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(a.warmup):
-        one_step(s)
-    sync()
-    ops.profile_enable(True)
-    t0 = time.perf_counter()
-    for s in range(a.warmup, a.warmup + a.steps):
-        one_step(s)
-    sync()
-    elapsed = time.perf_counter() - t0
-    ops.profile_enable(False)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stats = state.stats.cpu().tolist()
+    def max_over_ranks(self, seconds):
+        if not self.dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # live HIP-event timings of the dominant kernels inside the timed region (this rank)
-    deg = model.cfg.sh_deg
+    def comm(self):
+        from plenoctree_amd import dist as pdist
+        return pdist.Comm(self.world, self.rank, self.local_rank, "nccl" if self.dist else None)
+
+
+def read_kernels(ops, deg):
+    """Live HIP-event timings of the dominant kernels since profile_enable (this rank)."""
     names = ["mlp_fwd_kernel", "mlp_bwd_data_kernel", "wgrad_kernel<256,256>", "wgrad_kernel<other>"]
     # algorithmic FLOP per row: fwd 1.007 MFLOP; bwd(data) = 7 x 2*256*256 + 2*256*(3K+1);
     # wgrad 256x256 = 2*256*256 per launch-row
@@ -188,10 +195,148 @@ def main():
         if flop_row[tag]:
             ent["tflops"] = rows * flop_row[tag] / (ms * 1e-3) / 1e12
         kernels.append(ent)
+    return kernels
+
+
+def run_train(job, preset, steps, warmup):
+    """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats."""
+    from plenoctree_amd import ops
+    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
+    a = job.a
+    per_gpu = a.batch if a.scaling == "weak" else a.batch // job.world
+    args = flags_for(preset, per_gpu)
+    model, params = models.construct_nerf(args, job.device)
+    state = models.TrainState(model.cfg, params)
+    dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
+
+    def one_step(step):
+        batch = next(dataset)
+        lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps)
+        models.train_step(model, state, batch, lr, randomized=True, seed=(step << 8) | job.rank,
+                          world_size=job.world, all_reduce=job.all_reduce_sum if job.dist else None)
+
+    for s in range(warmup):
+        one_step(s)
+    job.sync()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        one_step(s)
+    job.sync()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    elapsed = job.max_over_ranks(elapsed)
+    deg = model.cfg.sh_deg
+    out = {"elapsed": elapsed, "per_gpu": per_gpu, "deg": deg, "kernels": read_kernels(ops, deg),
+           "stats": dict(zip(utils.Stats._fields, state.stats.cpu().tolist())), "args": args,
+           "model": model, "state": state, "dataset": dataset}
+    return out
+
+
+def run_render(job, tr, iters=20):
+    """The eval path (nerf_sh/eval.py -> utils.render_image): pxo_render_fwd on `batch` rays per GPU per call,
+    deterministic sampling (eval.py:57)."""
+    from plenoctree_amd import ops
+    model, state = tr["model"], tr["state"]
+    batch = next(tr["dataset"])
+    rays = batch["rays"]
+    for _ in range(2):
+        model.apply(state, rays, False)
+    job.sync()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model.apply(state, rays, False)
+    job.sync()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    ops.profile_enable(False)
+    read_kernels(ops, tr["deg"])          # drain the event records
+    rps = tr["per_gpu"] * job.world * iters / elapsed
+    return {"value": rps, "unit": "rays/s", "calls": iters, "rays_per_call_per_gpu": tr["per_gpu"],
+            "ms_per_call": 1e3 * elapsed / iters,
+            "frac": rps / job.world * FLOP_RENDER_PER_RAY[tr["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+
+
+def run_grid512(job, tr):
+    """BASELINE configs[4]: step 1 of octree.extraction at init_grid_depth 8 (octree/extraction.py:288-352):
+    sigma of MLP_1 on the 512^3 grid (x-slabs sharded over the ranks + all-gather), the weight mask over the 100
+    training views (cameras sharded + max-all-reduce) and the tree build."""
+    from plenoctree_amd import octree_ops as oops
+    from plenoctree_amd.octree import extraction
+    from plenoctree_amd.octree.svox import N3Tree
+    model, state, dataset = tr["model"], tr["state"], tr["dataset"]
+    comm = job.comm()
+    reso, center, radius = 512, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5]
+    state.repack(need_bwd=False)
+    extraction.grid_sigma(model, state, 64, center, radius, comm)       # warm-up (small grid)
+    job.sync()
+    t0 = time.perf_counter()
+    sig = extraction.grid_sigma(model, state, reso, center, radius, comm)
+    job.sync()
+    t_grid = job.max_over_ranks(time.perf_counter() - t0)
+    tree = N3Tree(N=2, data_dim=1 + 3 * (tr["deg"] + 1) ** 2, init_refine=0, depth_limit=8, radius=radius,
+                  center=center, data_format=f"SH{(tr['deg'] + 1) ** 2}", map_location=job.device)
+    t0 = time.perf_counter()
+    weights = extraction.calculate_grid_weights(dataset, sig, reso, tree.invradius, tree.offset, 1e-4, comm)
+    job.sync()
+    t_weight = job.max_over_ranks(time.perf_counter() - t0)
+    # an untrained network has no surfaces: threshold sigma at its median so that the tree build sees a realistic
+    # half-occupied mask (the build time does not depend on which voxels are set, only on how many)
+    t0 = time.perf_counter()
+    mask = oops.threshold_mask(sig, float(sig[::4099].median()))
+    tree.refine_from_mask(mask)
+    job.sync()
+    t_tree = job.max_over_ranks(time.perf_counter() - t0)
+    n_pts = reso ** 3
+    tflops = n_pts * FLOP_SIGMA_PER_POINT / t_grid / 1e12
+    del weights, mask, sig
+    return {"points": n_pts, "grid_ms": 1e3 * t_grid, "tflops": tflops,
+            "frac": tflops / job.world / PEAK_F32_MFMA_TFLOPS, "weight_mask_ms": 1e3 * t_weight,
+            "weight_mask_views": int(dataset.size), "tree_build_ms": 1e3 * t_tree,
+            "tree_nodes": int(tree.n_internal), "sharding": f"x-slabs over {job.world} GPU(s) + all-gather"}
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU; the HIP path has no CPU fallback")
+    job = Job(a)
+    rank = job.rank
+
+    from plenoctree_amd import build
+    if rank == 0:
+        build.build(verbose=False)
+    if job.dist:
+        job.dist.barrier()
+
+    tr = run_train(job, a.preset, a.steps, a.warmup)
+    extras = {}
+    if not a.no_extras:
+        extras["render_fwd"] = run_render(job, tr)
+        extras["grid512"] = run_grid512(job, tr)
+        other = "tt" if a.preset == "blender" else "blender"
+        tr["state"] = tr["dataset"] = None          # release the headline workspace before the second preset
+        torch.cuda.empty_cache()
+        k2 = max(10, a.steps // 4)
+        t2 = run_train(job, other, k2, 3)
+        v2 = t2["per_gpu"] * world * k2 / t2["elapsed"]
+        extras["tt_sh25" if other == "tt" else "blender_sh16"] = {
+            "value": v2, "unit": "rays/s", "steps": k2, "ms_per_step": 1e3 * t2["elapsed"] / k2,
+            "frac": v2 / world * FLOP_TRAIN_PER_RAY[t2["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            "mlp_fwd_tflops": t2["kernels"][0]["tflops"] if t2["kernels"] else None,
+            "workload": "nerf_sh/config/tt.yaml: SH25, near 0, far 4, sparsity_length 0.2, sparsity_radius 5"
+                        if other == "tt" else "nerf_sh/config/blender.yaml"}
+        t2 = None
 
     if rank == 0:
-        total_rays = per_gpu * world * a.steps
-        value = total_rays / elapsed
+        per_gpu, deg, kernels = tr["per_gpu"], tr["deg"], tr["kernels"]
+        elapsed = tr["elapsed"]
+        value = per_gpu * world * a.steps / elapsed
         dom = kernels[0] if kernels else None            # mlp_fwd_kernel: largest single launch of the step
         roofline = None
         if dom:
@@ -210,16 +355,18 @@ def main():
                                    "800x800 synthetic views, sparsity 10k pts, Adam",
                        "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
                        "parallelism": f"dp{world}"},
+            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": 1 if world > 1 else 0,
             "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
-            "final_stats": dict(zip(utils.Stats._fields, stats)),
+            "final_stats": tr["stats"],
             "roofline": roofline, "kernels": kernels,
         }
+        out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, a.cpu_rays, a.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(tr["args"], a.cpu_rays, a.cpu_steps)
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if job.dist:
+        job.dist.barrier()
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

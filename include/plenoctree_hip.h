@@ -161,6 +161,11 @@ int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int
 int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pixel_ids, int64_t B,
                       float* origins, float* directions, float* viewdirs, void* stream);
 
+/* The same for the `image_batching` sampler (nerf_sh/nerf/datasets.py:137-141,152-157: rays of ALL
+ * images flattened into one table): c2w [n_cams,3,4], ray id r -> camera r / (W*H), pixel r % (W*H). */
+int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids,
+                            int64_t B, float* origins, float* directions, float* viewdirs, void* stream);
+
 /* Step 2 of the extraction (octree/extraction.py:391-393, SH/SG formats): mean over the S samples
  * of each leaf of cat([raw_rgb, raw_sigma]); out [n_cells, 3K+1]. */
 int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, int64_t n_cells,

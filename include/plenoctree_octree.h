@@ -99,6 +99,11 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 /* ---- octree volume renderer  (VolumeRenderer.render_persp / render; octree/nerf/utils.py:456-474,
  *      octree/optimization.py:174-216) ---- */
 
+/* Lanes of a wave that cooperate on one ray in the forward / backward renderer launches: 4, 8 or 16, or 0 for
+ * the measured default (8 forward, 16 backward).  A tuning knob (results are identical up to the SH summation
+ * order); process-wide. */
+int pxo_octree_set_lanes_per_ray(int forward, int backward);
+
 /* Forward.  Rays come either from `cam` (cam != NULL: B must be width*height, ray r = pixel
  * (r % width, r / width), out [H,W,3]) or from explicit arrays origins/dirs/viewdirs [B,3] in world
  * space with unit dirs (cam == NULL).  out_rgb [B,3]. */
@@ -109,7 +114,8 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
  * [n_internal,2,2,2,D] -- zero it first (optimizer.zero_grad(), octree/optimization.py:221-224).
  * Training semantics: exact marching (stop_thresh is ignored: no early-stop rescale).
  * out_rgb: the [B,3] result of pxo_octree_render_fwd for the same rays with the same exact options, or NULL
- * (the kernel then re-marches once more to recover it). */
+ * (the kernel then re-marches once more to recover it).  Passing out_rgb together with opts->stop_thresh > 0
+ * is rejected (PXO_ERR_ARG): an early-stopped image is not the image this gradient belongs to. */
 int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
                           const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
                           const float* grad_out, float* grad_data, void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "pxo_uniform": (c_int, [c_uint64, c_uint64, c_int64, c_float, c_float, P, P]),
     "pxo_randint": (c_int, [c_uint64, c_uint64, c_int64, c_int64, P, P]),
     "pxo_generate_rays": (c_int, [P, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
+    "pxo_generate_rays_multi": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
     "pxo_mean_over_samples": (c_int, [CFG, P, P, c_int64, c_int, P, P]),
     "pxo_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_int64, c_float, P]),
     "pxo_render_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
@@ -115,6 +116,7 @@ SIGNATURES = {
     "pxo_grid_weight_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "pxo_grid_weight_render": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
                                        F3, F3, P, P, c_size_t, P]),
+    "pxo_octree_set_lanes_per_ray": (c_int, [c_int, c_int]),
     "pxo_octree_render_fwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,

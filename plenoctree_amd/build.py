@@ -13,14 +13,29 @@ SOURCE_FLAGS = {"octree_kernels.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+STAMP = os.path.join(HERE, "libplenoctree_hip.stamp")   # travels with the .so (git-ignored, not gpurun-ignored)
+
+
+def _source_hash():
+    """sha256 over every file the library is compiled from, plus the flags."""
+    import hashlib
+    h = hashlib.sha256(repr((FLAGS, sorted(SOURCE_FLAGS.items()))).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     deps.append(os.path.join(HERE, "..", "include", "plenoctree_hip.h"))
     deps.append(os.path.join(HERE, "..", "include", "plenoctree_octree.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale():
+    """The library is current iff the stamp written next to the objects matches the sources' hash."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=True, extra_flags=(), suffix=""):
@@ -64,6 +79,9 @@ def _build(force, verbose, extra_flags, objdir):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if objdir == "build":
+        with open(STAMP, "w") as f:
+            f.write(_source_hash() + "\n")
     return LIB
 
 

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   }
   if (MODE == 1 && miss) return;
 
-  // per-lane channel ownership: data index l + 16 j -> (channel, SH component)
+  // per-lane channel ownership: data index l + ROW j -> (channel, SH component)
   if (l == 0) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
   __builtin_amdgcn_wave_barrier();
   const int nload = (D - 1 + kRow - 1) / kRow;
@@ -831,12 +831,14 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // duplicated traversal arithmetic, coefficient rows still 32-byte coalesced); backward 10.9 / 14.0 / 22.1 ms (the
 // gradient scatter wants the widest atomic rows); SH25: forward 4.34 / 4.04 ms, backward 13.9 / 17.8 ms for 16 / 8.
 // So: forward 8 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+static int g_row_override[2] = {0, 0};   // [forward, backward]; 0 = the measured default
 static int render_row(bool backward, int data_dim) {
   static const int forced = [] {
     const char* e = getenv("PXO_OCT_ROW");
     const int v = e ? atoi(e) : 0;
     return (v == 4 || v == 8 || v == 16) ? v : 0;
   }();
+  if (g_row_override[backward ? 1 : 0]) return g_row_override[backward ? 1 : 0];
   if (forced) return forced;
   (void)data_dim;
   return backward ? 16 : 8;
@@ -876,6 +878,14 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
   return PXO_OK;
 }
 
+int pxo_octree_set_lanes_per_ray(int forward, int backward) {
+  auto ok = [](int v) { return v == 0 || v == 4 || v == 8 || v == 16; };
+  PXO_REQUIRE(ok(forward) && ok(backward), "pxo_octree_set_lanes_per_ray: lanes must be 0 (default), 4, 8 or 16");
+  g_row_override[0] = forward;
+  g_row_override[1] = backward;
+  return PXO_OK;
+}
+
 int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
                           const float* viewdirs, int64_t B, const PxoRenderOpts* opts, float* out_rgb, void* stream) {
   RenderArgs A;
@@ -902,6 +912,11 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
   if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd", true, A, grid, row)) return rc;
   if (B == 0) return PXO_OK;
   PXO_REQUIRE(grad_out && grad_data, "pxo_octree_render_bwd: null pointer");
+  // the gradient pass marches exactly (no early stop, no 1/(1-T) rescale): a forward image made with
+  // stop_thresh > 0 is not the image whose gradient this is
+  PXO_REQUIRE(out_rgb == nullptr || opts->stop_thresh == 0.0f,
+              "pxo_octree_render_bwd: out_rgb must come from an exact march (stop_thresh == 0), got stop_thresh %g",
+              (double)opts->stop_thresh);
   switch (row) {
     case 4: hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;

@@ -135,6 +135,19 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
   return check_launch("fill");
 }
 
+// y += a * x  (weight-decay term of loss_fn, train.py:101-114: d/dp [wd * sum(p^2)/n] = 2 wd p / n)
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+int launch_axpy(float* y, const float* x, int64_t n, float a, hipStream_t s) {
+  if (n == 0) return PXO_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, x, n, a);
+  return check_launch("axpy");
+}
+
 // flax.optim.Adam.apply_param_gradient with weight_decay = 0:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; t = step+1
 //   p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)

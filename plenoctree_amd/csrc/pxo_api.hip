@@ -338,7 +338,16 @@ int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t
                       float* origins, float* directions, float* viewdirs, void* stream) {
   PXO_REQUIRE(B >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && origins && directions && viewdirs,
               "pxo_generate_rays: bad arguments");
-  return launch_generate_rays(c2w, W, H, focal, pixel_ids, B, origins, directions, viewdirs, (hipStream_t)stream);
+  return launch_generate_rays(c2w, 1, W, H, focal, pixel_ids, B, origins, directions, viewdirs, (hipStream_t)stream);
+}
+
+int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids, int64_t B,
+                            float* origins, float* directions, float* viewdirs, void* stream) {
+  PXO_REQUIRE(B >= 0 && n_cams >= 1 && W >= 1 && H >= 1 && focal > 0.f && c2w && ray_ids && origins && directions &&
+                  viewdirs,
+              "pxo_generate_rays_multi: bad arguments");
+  return launch_generate_rays(c2w, n_cams, W, H, focal, ray_ids, B, origins, directions, viewdirs,
+                              (hipStream_t)stream);
 }
 
 int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S,
@@ -443,6 +452,8 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   } else {
     PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
   }
+  if (cfg->weight_decay_mult != 0.f)   // + weight_decay_mult * weight_l2 (train.py:101-114)
+    PXO_TRY(launch_axpy(grads, params, 2 * n_mlp, 2.f * cfg->weight_decay_mult / (float)(2 * n_mlp), s));
   PXO_TRY(launch_sumsq(params, 2 * n_mlp, sc + 3, s));
   PXO_TRY(launch_finalize_stats(sc + 0, sc + 1, sc + 2, sc + 3, B, Nf > 0, t.n_sp, cfg->sparsity_weight, 2 * n_mlp,
                                 stats, s));

@@ -153,8 +153,8 @@ int launch_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const fl
                                float* d_raw_sigma, hipStream_t s);
 int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const float* d, int64_t B,
                       int Nc, int Nf, const float* u, float* z_out, float* pts, hipStream_t s);
-int launch_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pix, int64_t B, float* o,
-                         float* d, float* v, hipStream_t s);
+int launch_generate_rays(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* pix, int64_t B,
+                         float* o, float* d, float* v, hipStream_t s);
 int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, hipStream_t s);
 int launch_mean_samples(const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S, int C, float* out,
                         hipStream_t s);
@@ -173,5 +173,6 @@ int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* s
                           const float* sumsq, int64_t B, int has_fine, int64_t n_sp, float sp_weight,
                           int64_t n_params, float* stats, hipStream_t s);
 int launch_fill(float* p, int64_t n, float v, hipStream_t s);
+int launch_axpy(float* y, const float* x, int64_t n, float a, hipStream_t s);
 
 }  // namespace pxo

@@ -379,12 +379,22 @@ int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const 
 // pixel id p -> x = p % W, y = p / W (integer pixel centres), dir_cam = [(x-W/2)/f, -(y-H/2)/f, -1],
 // direction = R dir_cam (not normalised), origin = c2w[:3,3], viewdir = direction / |direction|
 // ------------------------------------------------------------------------------------------
-__global__ void generate_rays_kernel(const float* __restrict__ c2w, int W, int H, float focal,
+// With n_cams > 1 the ids index the flattened [n_cams, H*W] ray table of the image_batching sampler
+// (nerf_sh/nerf/datasets.py:137-141,152-157) and c2w is [n_cams,3,4].
+__global__ void generate_rays_kernel(const float* __restrict__ c2w_all, int n_cams, int W, int H, float focal,
                                      const int64_t* __restrict__ pix, int64_t B, float* __restrict__ o,
                                      float* __restrict__ d, float* __restrict__ v) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
-  const int64_t p = pix ? pix[i] : i;
+  int64_t p = pix ? pix[i] : i;
+  const float* __restrict__ c2w = c2w_all;
+  if (n_cams > 1) {
+    const int64_t hw = (int64_t)W * H;
+    int64_t cam = p / hw;
+    if (cam >= n_cams) cam = n_cams - 1;
+    p -= cam * hw;
+    c2w += cam * 12;
+  }
   const float x = (float)(p % W), y = (float)(p / W);
   const float cx = (x - (float)W * 0.5f) / focal, cy = -(y - (float)H * 0.5f) / focal, cz = -1.f;
   float dir[3];
@@ -400,11 +410,11 @@ __global__ void generate_rays_kernel(const float* __restrict__ c2w, int W, int H
   for (int a = 0; a < 3; ++a) v[i * 3 + a] = dir[a] / n;
 }
 
-int launch_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pix, int64_t B, float* o,
-                         float* d, float* v, hipStream_t s) {
+int launch_generate_rays(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* pix, int64_t B,
+                         float* o, float* d, float* v, hipStream_t s) {
   if (B == 0) return PXO_OK;
-  hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c2w, W, H, focal, pix,
-                     B, o, d, v);
+  hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c2w, n_cams, W, H, focal,
+                     pix, B, o, d, v);
   return check_launch("generate_rays");
 }
 

@@ -61,6 +61,7 @@ class Dataset:
         self.device = device
         self.batch_size = batch_size if batch_size is not None else args.batch_size
         self.white_bkgd = bool(args.white_bkgd)
+        self.image_batching = bool(getattr(args, "image_batching", False))
         self.rng = np.random.RandomState(seed)      # np.random.seed(20201473 + host_id), train.py:128
         self.seed, self.draws = int(seed), 0
         self.it = 0
@@ -98,6 +99,8 @@ class Dataset:
         return self
 
     def __next__(self):
+        if self.split == "train" and self.image_batching:
+            return self._next_train_all_images()
         if self.split == "train":
             # datasets.py:159-166: one random image, batch_size random pixels (with replacement)
             image_index = int(self.rng.randint(0, self.n_examples))
@@ -114,6 +117,31 @@ class Dataset:
         idx = self.it
         self.it = (self.it + 1) % self.n_examples
         return self.get_image(idx)
+
+    def _next_train_all_images(self):
+        """image_batching (datasets.py:137-141,152-157): batch_size rays drawn from the flattened table of the rays
+        of ALL images.  The table itself is never materialised: a ray id is (camera, pixel) and the ray is computed."""
+        hw = self.h * self.w
+        if self.device.type == "cuda":
+            from ... import ops
+            self.draws += 1
+            ids = ops.randint(self.seed, self.draws, self.batch_size, self.n_examples * hw, device=self.device)
+            if not hasattr(self, "_c2w_dev"):
+                self._c2w_dev = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[:, :3, :4])).to(self.device)
+            rays = utils.Rays(*ops.generate_rays_multi(self._c2w_dev, self.w, self.h, self.focal, ids))
+        else:
+            ids = torch.from_numpy(self.rng.randint(0, self.n_examples * hw, (self.batch_size,))).to(self.device)
+            cam = torch.div(ids, hw, rounding_mode="floor")
+            parts = [self._rays_for(int(c), ids[cam == c] - int(c) * hw) for c in torch.unique(cam).tolist()]
+            order = torch.argsort(torch.cat([torch.nonzero(cam == c).reshape(-1) for c in torch.unique(cam).tolist()]))
+            rays = utils.Rays(*[torch.cat([getattr(p, f) for p in parts])[order].contiguous() for f in utils.Rays._fields])
+        return {"pixels": self._pixels_flat(ids, rays), "rays": rays}
+
+    def _pixels_flat(self, ids, rays):
+        """Target colours of ids into the flattened [n_examples * H*W] pixel table."""
+        if getattr(self, "images", None) is not None:
+            return self.images.reshape(-1, 3)[ids].contiguous()
+        return self._render(None, None, rays)
 
     def get_image(self, idx):
         ray_indices = torch.arange(self.h * self.w, device=self.device)

@@ -23,8 +23,11 @@ class TrainState:
         self.m = torch.zeros_like(params)
         self.v = torch.zeros_like(params)
         self.step = int(step)            # number of updates applied (flax optimizer.state.step)
-        self.grads = torch.zeros_like(params)
-        self.stats = torch.zeros(6, dtype=torch.float32, device=params.device)
+        # gradient arena with the 6 Stats in its tail: lax.pmean(grad) and lax.pmean(stats)
+        # (train.py:117-118) are then ONE sum-all-reduce over `reduce_buf`
+        self.reduce_buf = torch.zeros(params.numel() + 8, dtype=torch.float32, device=params.device)
+        self.grads = self.reduce_buf[:params.numel()]
+        self.stats = self.reduce_buf[params.numel():params.numel() + 6]
         self.n_mlp = params.numel() // 2
         self.packed = [None, None]
         self._ws = None
@@ -120,8 +123,8 @@ def train_step(model, state, batch, lr, randomized=True, t_rand=None, u=None, sp
                world_size=1, all_reduce=None):
     """One optimisation step (nerf_sh/train.py:51-121) on this rank's shard of the batch.
 
-    loss_fn + value_and_grad run in pxo_train_fwd_bwd; `all_reduce` (RCCL sum over ranks of the
-    flat gradient arena and of the 6 stats) implements lax.pmean (train.py:117-118); Adam
+    loss_fn + value_and_grad run in pxo_train_fwd_bwd; `all_reduce` (one RCCL sum over ranks of the
+    flat gradient arena with the 6 stats in its tail) implements lax.pmean (train.py:117-118); Adam
     (train.py:119) and the re-pack of the weight images follow.  Returns the device tensor
     stats[6] = (loss, psnr, loss_c, loss_sp, psnr_c, weight_l2); its values are only read by
     the host when logging."""
@@ -134,8 +137,7 @@ def train_step(model, state, batch, lr, randomized=True, t_rand=None, u=None, sp
                       seed=seed)
     scale = 1.0
     if world_size > 1:
-        all_reduce(state.grads)
-        all_reduce(state.stats)
+        all_reduce(state.reduce_buf)        # gradients + stats, one RCCL call
         state.stats.mul_(1.0 / world_size)
         scale = 1.0 / world_size
     ops.adam_step(state.params, state.m, state.v, state.grads, lr, state.step, grad_scale=scale)

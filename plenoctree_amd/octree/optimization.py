@@ -4,7 +4,10 @@ the training images through the octree renderer.
 Per image (reference :214-230): render -> clamp -> MSE -> backward -> optimizer step.  Here: HIP render
 forward, HIP clamped-MSE gradient, HIP render backward (atomic scatter into the tree gradient), HIP SGD/Adam.
 With N GPUs each image's gradient is computed on one rank in turn and summed with one RCCL all-reduce per
-group of N images (a mini-batch of N images; N = 1 reproduces the reference's per-image steps).
+group of N images; N = 1 reproduces the reference's per-image steps.  `--dp_grad_reduce sum` (default) applies the
+SUM of the group's gradients at the unchanged lr -- to first order the reference's N consecutive per-image steps
+(linear lr scaling), so an epoch moves the tree as far as on one GPU; `mean` averages instead (an N-image
+mini-batch at the same lr: N times smaller effective updates per epoch).  Adam is invariant to the choice.
 
     python -m plenoctree_amd.octree.optimization --input tree.npz --output tree_opt.npz --config blender --data_dir ...
 """
@@ -37,6 +40,7 @@ def define_flags():
     a("--continue_on_decrease", action="store_true")
     a("--renderer_step_size", type=float, default=1e-4)
     a("--no_early_stop", action="store_true")
+    a("--dp_grad_reduce", type=str, default="sum", choices=["sum", "mean"])     # multi-GPU only (see module doc)
     return p
 
 
@@ -78,7 +82,7 @@ def run_validation(renderer, c2ws, images, H, W, focal, comm):
     for j in range(comm.rank, len(c2ws), comm.world):
         im = renderer.render_persp(c2ws[j], width=W, height=H, fx=focal, fast=False)
         sse, _ = oops.image_mse(im, images[j], want_grad=False)
-        acc[0] += utils.compute_psnr(float(sse) / im.numel())
+        acc[0] += -10.0 * torch.log10(sse.double().reshape(()) / im.numel())    # on the device: no host sync per image
         acc[1] += 1
     comm.all_reduce_sum(acc)
     return float(acc[0] / acc[1])
@@ -87,7 +91,7 @@ def run_validation(renderer, c2ws, images, H, W, focal, comm):
 def fit(args, tree, train, val, H, W, focal, comm, say=print):
     """The epoch loop of octree/optimization.py:189-243.  train/val = (c2w [n,4,4], list of [H,W,3] images).
     Rank r takes image j0 + r of every group of `world` images; the group's gradients are summed with one
-    all-reduce and applied as one step on their mean.  Returns (history, best tree on the CPU or None)."""
+    all-reduce and applied as one step (on their sum or mean, --dp_grad_reduce).  Returns (history, best tree on the CPU or None)."""
     (train_c2w, train_gt), (test_c2w, test_gt) = train, val
     renderer = VolumeRenderer(tree, step_size=args.renderer_step_size)
     opt = TreeOptimizer(tree, args)
@@ -103,10 +107,10 @@ def fit(args, tree, train, val, H, W, focal, comm, say=print):
             opt.zero_grad()
             if j < n_train:
                 sse = train_image(renderer, opt, train_c2w[j], train_gt[j], H, W, focal)
-                tpsnr += utils.compute_psnr(float(sse) / (H * W * 3))
+                tpsnr += -10.0 * torch.log10(sse.double().reshape(()) / (H * W * 3))   # device-side, read once per epoch
             n_imgs = min(comm.world, n_train - j0)
             comm.all_reduce_sum(opt.grad)
-            opt.step(grad_scale=1.0 / n_imgs)
+            opt.step(grad_scale=1.0 if getattr(args, "dp_grad_reduce", "sum") == "sum" else 1.0 / n_imgs)
         comm.all_reduce_sum(tpsnr)
         train_psnr = float(tpsnr) / n_train
         say("epoch", epoch, "** train_psnr", train_psnr, flush=True)

@@ -119,6 +119,11 @@ def _camera(c2w, width, height, fx, fy):
     return cam, c2w          # keep c2w alive for the duration of the call
 
 
+def set_lanes_per_ray(forward=0, backward=0):
+    """Lanes per ray of the renderer launches (4 / 8 / 16; 0 = measured default 8 forward, 16 backward)."""
+    check(_lib.load().pxo_octree_set_lanes_per_ray(int(forward), int(backward)), "pxo_octree_set_lanes_per_ray")
+
+
 def octree_render_persp(tree, c2w, width, height, fx, opts, fy=None):
     """[H,W,3] image of a pinhole camera (VolumeRenderer.render_persp)."""
     _require_gpu()

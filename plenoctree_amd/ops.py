@@ -314,6 +314,20 @@ def generate_rays(c2w, W, H, focal, pixel_ids=None, count=None):
     return o, d, v
 
 
+def generate_rays_multi(c2w_all, W, H, focal, ray_ids):
+    """Rays of ids into the flattened [n_cams, H*W] table (image_batching): (origins, directions, viewdirs)."""
+    _require_gpu()
+    if ray_ids.dtype != torch.int64:
+        raise PxoError("ray_ids must be int64")
+    c2w_all = c2w_all[:, :3, :4].contiguous()
+    B = ray_ids.shape[0]
+    dev = c2w_all.device
+    o, d, v = _new(B, 3, device=dev), _new(B, 3, device=dev), _new(B, 3, device=dev)
+    check(_lib.load().pxo_generate_rays_multi(_f(c2w_all), c2w_all.shape[0], W, H, float(focal), _p(ray_ids), B,
+                                              _f(o), _f(d), _f(v), _stream()), "pxo_generate_rays_multi")
+    return o, d, v
+
+
 def mean_over_samples(cfg, raw_rgb, raw_sigma, samples_per_cell, out=None):
     _require_gpu()
     n = raw_sigma.numel() // samples_per_cell

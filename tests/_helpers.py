@@ -1,0 +1,137 @@
+"""Shared helpers of the -m gpu parity tests (HIP path through the C ABI vs the CPU oracle)."""
+import numpy as np   # noqa: F401
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no ROCm GPU visible: -m gpu tests must run on the MI355X box")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from plenoctree_amd import ops
+    return ops
+
+
+def close(name, got, want, rtol=2e-4, atol=2e-5):
+    got = got.detach().cpu().double().reshape(-1)
+    want = want.detach().cpu().double().reshape(-1)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite values in HIP output"
+    assert torch.isfinite(want).all(), f"{name}: non-finite values in the oracle output"
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{got.numel()} outside tol; worst idx {i}: got {got[i]:.8g} want {want[i]:.8g} "
+            f"(abs err {err[i]:.3g}, max abs err {err.max():.3g}, ref max {want.abs().max():.3g})")
+
+
+def make_params(cfg, seed=3, bias_scale=0.1, dtype=torch.float32):
+    """Glorot kernels, N(0, bias_scale^2) biases, and a sigma head scaled so that rays see a mix
+    of empty, translucent and opaque samples."""
+    gen = torch.Generator().manual_seed(seed)
+    params = [O.init_mlp_params(cfg, gen, dtype), O.init_mlp_params(cfg, gen, dtype)]
+    out = []
+    for mlp in params:
+        for li, (w, b) in enumerate(mlp):
+            if li == cfg.net_depth:          # Dense_8, sigma head
+                w = w * 8.0
+            out.append(w.reshape(-1))
+            out.append(b + bias_scale * torch.randn(b.shape, generator=gen, dtype=dtype))
+    flat = torch.cat(out)
+    # A freshly initialised MLP has an almost constant raw sigma over space; shift each sigma-head
+    # bias so that its median over the scene volume is slightly positive (otherwise relu(sigma) = 0
+    # everywhere and every gradient vanishes).
+    n = flat.numel() // 2
+    b8 = sum(fi * fo + fo for fi, fo in O.layer_shapes(cfg)[:8]) + O.layer_shapes(cfg)[8][0]
+    pts = (torch.rand(2048, 3, generator=gen, dtype=dtype) * 2 - 1) * 2.0
+    for mi in range(2):
+        mlp = O.unflatten_params(flat, cfg)[mi]
+        _, rs = O.mlp_forward(mlp, O.posenc(pts, 0, 10), cfg)
+        flat[mi * n + b8] += 0.2 * float(rs.std()) + 0.3 - float(rs.median())
+    return flat
+
+
+def make_rays(B, seed=5, dtype=torch.float32):
+    gen = torch.Generator().manual_seed(seed)
+    cam = torch.randn(B, 3, generator=gen, dtype=dtype)
+    cam = 4.0 * cam / cam.norm(dim=-1, keepdim=True)
+    target = 0.5 * (torch.rand(B, 3, generator=gen, dtype=dtype) - 0.5)
+    d = target - cam
+    d = d / d.norm(dim=-1, keepdim=True) * (1.0 + 0.1 * torch.rand(B, 1, generator=gen, dtype=dtype))
+    v = d / d.norm(dim=-1, keepdim=True)
+    return O.Rays(cam, d, v)
+
+
+def pxo_cfg(ops, cfg):
+    return ops.make_cfg(num_coarse_samples=cfg.num_coarse_samples, num_fine_samples=cfg.num_fine_samples,
+                        sh_deg=cfg.sh_deg, white_bkgd=int(cfg.white_bkgd), lindisp=int(cfg.lindisp),
+                        sparsity_npoints=cfg.sparsity_npoints, near_=cfg.near, far_=cfg.far,
+                        sparsity_weight=cfg.sparsity_weight, sparsity_length=cfg.sparsity_length,
+                        sparsity_radius=cfg.sparsity_radius, weight_decay_mult=cfg.weight_decay_mult)
+
+
+def split_mlp(flat, cfg, which):
+    n = flat.numel() // 2
+    return flat[which * n:(which + 1) * n].contiguous()
+
+
+def _psnr(a, b):
+    return float(-10.0 * torch.log10(((a.double() - b.double()) ** 2).mean()))
+
+
+def oracle_render_chunked(flat, rays, cfg, t_rand, u, dtype=torch.float32, chunk=1024):
+    """O.render over ray chunks (bounds host memory at BASELINE sizes): [(rgb,disp,acc)_c, (rgb,disp,acc)_f]."""
+    cast = lambda t: None if t is None else t.to(dtype)
+    params = O.unflatten_params(flat.to(dtype), cfg)
+    parts = []
+    with torch.no_grad():
+        for i0 in range(0, rays.origins.shape[0], chunk):
+            sl = slice(i0, i0 + chunk)
+            r = O.Rays(*[cast(x[sl]) for x in rays])
+            parts.append(O.render(params, r, cfg, None if t_rand is None else cast(t_rand[sl]),
+                                  None if u is None else cast(u[sl])))
+    return [tuple(torch.cat([p[lvl][j] for p in parts]) for j in range(3)) for lvl in range(len(parts[0]))]
+
+
+def oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_points, dtype=torch.float32, chunk=512):
+    """O.loss_fn + its gradient (nerf_sh/train.py:68-116) accumulated over ray chunks.  loss_fn's terms are means over
+    rays, i.e. sums of per-chunk sums / (3B): the chunked evaluation is the same function (only the float summation
+    order differs) with bounded host memory.  Returns (stats dict of floats, grad)."""
+    cast = lambda t: None if t is None else t.to(dtype)
+    p = flat.to(dtype).detach().clone().requires_grad_(True)
+    B = px.shape[0]
+    fine = cfg.num_fine_samples > 0
+    sse = [0.0, 0.0]
+    for i0 in range(0, B, chunk):
+        sl = slice(i0, i0 + chunk)
+        r = O.Rays(*[cast(x[sl]) for x in rays])
+        ret = O.render(O.unflatten_params(p, cfg), r, cfg, cast(t_rand[sl]), cast(u[sl]) if fine else None)
+        tgt = cast(px[sl])
+        terms = [((lvl[0] - tgt) ** 2).sum() for lvl in ret]
+        (sum(terms) / (3.0 * B)).backward()
+        sse[0] += float(terms[-1]); sse[1] += float(terms[0]) if fine else 0.0
+    params = O.unflatten_params(p, cfg)
+    tail = torch.zeros((), dtype=dtype)
+    loss_sp = 0.0
+    if cfg.sparsity_weight > 0.0:
+        _, sig = O.eval_points_raw(params, cast(sp_points), cfg)
+        lsp = cfg.sparsity_weight * (1.0 - torch.exp(-cfg.sparsity_length * torch.relu(sig)).mean())
+        tail = tail + lsp
+        loss_sp = float(lsp)
+    leaves = [t for mlp in params for pair in mlp for t in pair]
+    weight_l2 = sum((z ** 2).sum() for z in leaves) / sum(z.numel() for z in leaves)
+    tail = tail + cfg.weight_decay_mult * weight_l2
+    tail.backward()
+    loss, loss_c = sse[0] / (3.0 * B), sse[1] / (3.0 * B)
+    psnr = lambda m: -10.0 * float(np.log10(m)) if m > 0 else 0.0
+    stats = dict(loss=loss, psnr=psnr(loss), loss_c=loss_c if fine else 0.0, loss_sp=loss_sp,
+                 psnr_c=psnr(loss_c) if fine else 0.0, weight_l2=float(weight_l2))
+    return stats, p.grad.detach()

@@ -100,13 +100,22 @@ def _worker(rank, world, port, outdir):
     state = models.TrainState(pcfg, flat.clone())
     per = B_GLOBAL // world
     sl = slice(rank * per, (rank + 1) * per)
+    calls = []
+
+    def counted_all_reduce(t):
+        calls.append(t.numel())
+        comm.all_reduce_sum(t)
+
     for step in range(STEPS):
         t_rand, u, sp = rnd[step]
         batch = {"rays": utils.Rays(*[r[sl].contiguous() for r in rays]), "pixels": px[sl].contiguous()}
         lr = utils.learning_rate_decay(step, 5e-4, 5e-6, 100)
         models.train_step(model, state, batch, lr, t_rand=t_rand[sl].contiguous(), u=u[sl].contiguous(),
-                          sp_points=sp, world_size=comm.world, all_reduce=comm.all_reduce_sum)
+                          sp_points=sp, world_size=comm.world, all_reduce=counted_all_reduce)
     assert state.step == STEPS
+    # lax.pmean(grad) + lax.pmean(stats) (train.py:117-118) = exactly one collective per step: the gradient arena
+    # with the 6 stats in its tail
+    assert calls == [flat.numel() + 8] * STEPS, calls
     # render_image: padded chunks, per-rank slices, all-gather (nerf_sh/nerf/utils.py:357-371)
     H, W = 5, 7                                   # 35 rays: odd, chunk 16 -> padding on every chunk
     g = torch.Generator().manual_seed(3)

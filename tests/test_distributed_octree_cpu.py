@@ -136,7 +136,7 @@ def _problem():
     rs = np.random.RandomState(3)
     train_gt = [torch.from_numpy(rs.rand(H, W, 3).astype(np.float32)) for _ in range(N_TRAIN)]
     val_gt = [torch.from_numpy(rs.rand(H, W, 3).astype(np.float32)) for _ in range(N_VAL)]
-    args = types.SimpleNamespace(renderer_step_size=1e-2, sgd=True, lr=LR, sgd_momentum=0.0, sgd_nesterov=False,
+    args = types.SimpleNamespace(dp_grad_reduce="sum", renderer_step_size=1e-2, sgd=True, lr=LR, sgd_momentum=0.0, sgd_nesterov=False,
                                  num_epochs=EPOCHS, val_interval=1, continue_on_decrease=True, no_early_stop=True,
                                  samples_per_cell=3, chunk=48)
     return t, args, (torch.from_numpy(train_c2w), train_gt), (torch.from_numpy(val_c2w), val_gt)
@@ -180,7 +180,7 @@ def test_two_rank_octree_drivers_match_single_process():
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt"), weights_only=False) for r in range(world)]
     assert torch.equal(res[0]["data"], res[1]["data"])               # replicas stay identical
     assert res[0]["history"] == res[1]["history"] and res[0]["psnr"] == res[1]["psnr"]
-    # independent restatement: mean gradient of each group of `world` images, plain SGD
+    # independent restatement: summed gradient of each group of `world` images (--dp_grad_reduce sum), plain SGD
     t, args, (train_c2w, train_gt), (val_c2w, val_gt) = _problem()
     opt = T.RenderOptions(args.renderer_step_size)
     data = torch.from_numpy(t.data.copy()).double()
@@ -202,7 +202,7 @@ def test_two_rank_octree_drivers_match_single_process():
     for _ in range(EPOCHS):
         for j0 in range(0, N_TRAIN, world):
             group = list(range(j0, min(j0 + world, N_TRAIN)))
-            g = sum(grad_of(j) for j in group) / len(group)
+            g = sum(grad_of(j) for j in group)
             data = (data.float() - LR * g.float()).double()
         want_hist.append(val_psnr())
     got_hist = [h[2] for h in res[0]["history"]]

@@ -237,6 +237,42 @@ def test_octree_render_gradient_matches_oracle(K):
     close("image_mse grad", gi, ref_in.grad, rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_octree_render_every_lanes_per_ray_template(lanes):
+    """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 8 forward / 16 backward);
+    every instantiation is held to the same oracle bounds, forward and gradient, for SH16 and SH25."""
+    oops = _oops(); dev = _gpu()
+    try:
+        oops.set_lanes_per_ray(lanes, lanes)
+        for K in (16, 25):
+            t = _random_tree(3, 50 + K, K)
+            view, (child, data) = _device_tree(t, dev)
+            W, H, fx = 13, 9, 12.0
+            c2w = _pose(35.0, 20.0)
+            opt = T.RenderOptions(1e-3)
+            want = T.render_persp(t, c2w, W, H, fx, opt)
+            got = oops.octree_render_persp(view, torch.from_numpy(c2w).to(dev), W, H, fx, oops.render_opts(1e-3))
+            close(f"SH{K} image, {lanes} lanes", got, torch.from_numpy(want), rtol=0, atol=2e-5)
+            rs = np.random.RandomState(K + lanes)
+            o = (rs.randn(16, 3) * 3.0).astype(f32)
+            d = (-o + rs.randn(16, 3) * 0.3).astype(f32)
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            g = rs.randn(16, 3).astype(f32)
+            dd = torch.tensor(t.data.astype(np.float64), requires_grad=True)
+            out = T.render_rays_torch(t, dd, o, d, d, opt)
+            (out * torch.from_numpy(g.astype(np.float64))).sum().backward()
+            to = lambda a: torch.from_numpy(a).to(dev)
+            grad = torch.zeros_like(data)
+            oops.octree_render_rays_bwd(view, to(o), to(d), to(d), oops.render_opts(1e-3), to(g), grad)
+            wantg = dd.grad.float()
+            close(f"SH{K} d/d data, {lanes} lanes", grad, wantg, rtol=2e-3, atol=2e-6 * float(wantg.abs().max()) + 1e-7)
+    finally:
+        oops.set_lanes_per_ray(0, 0)
+    from plenoctree_amd import _lib
+    with pytest.raises(_lib.PxoError, match="lanes"):
+        oops.set_lanes_per_ray(5, 0)
+
+
 def test_sgd_step_matches_torch():
     oops = _oops(); dev = _gpu()
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -270,6 +306,11 @@ def test_octree_error_paths():
         oops.tree_view(keep[0], torch.zeros(3, 2, 2, 2, 12, device=dev), t.offset, t.invradius)
     with pytest.raises(PxoError, match="depth"):
         oops.tree_workspace_bytes(11)
+    # the gradient pass marches exactly: an early-stopped forward image is rejected at the C ABI
+    fast = oops.render_opts(1e-3, 1.0, 1e-2, 1e-2)
+    img = oops.octree_render_persp(view, c2w, 4, 4, 5.0, fast)
+    with pytest.raises(PxoError, match="stop_thresh"):
+        oops.octree_render_persp_bwd(view, c2w, 4, 4, 5.0, fast, torch.ones_like(img), torch.zeros_like(keep[1]), out_rgb=img)
 
 
 def _write_checkpoint(tmp_path, args, flat):

@@ -98,6 +98,23 @@ def test_blender_loader(tmp_path):
     np.testing.assert_allclose(ds.images[1].numpy().reshape(8, 8, 3), want, rtol=1e-6)
     b = next(ds)
     assert b["pixels"].shape == (16, 3)
+    # image_batching (datasets.py:137-141,152-157): rays drawn from the flattened table of ALL images; every
+    # drawn (ray, pixel) pair must be the pair of its own image
+    a.image_batching = True
+    ds_all = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=64)
+    b = next(ds_all)
+    full = [ds_all.get_image(i) for i in range(3)]
+    table_o = torch.cat([f["rays"].origins.reshape(-1, 3) for f in full])
+    table_d = torch.cat([f["rays"].directions.reshape(-1, 3) for f in full])
+    table_px = torch.cat([f["pixels"].reshape(-1, 3) for f in full])
+    seen = set()
+    for i in range(64):
+        hit = ((table_d - b["rays"].directions[i]).abs().sum(-1) < 1e-6) & ((table_o - b["rays"].origins[i]).abs().sum(-1) < 1e-6)
+        assert int(hit.sum()) == 1
+        j = int(hit.nonzero()[0])
+        seen.add(j // 64)
+        assert torch.equal(table_px[j], b["pixels"][i])
+    assert len(seen) > 1                       # one batch spans several images
 
 
 def test_nsvf_loader_on_a_synthetic_directory(tmp_path):

@@ -162,3 +162,29 @@ def test_dp_invariance_of_mean_of_shard_means():
         r = O.Rays(rays.origins[sl], rays.directions[sl], rays.viewdirs[sl])
         gs.append(O.loss_and_grad(flat, r, px[sl], cfg, t_rand[sl], u[sl], sp)[2])
     np.testing.assert_allclose(((gs[0] + gs[1]) / 2).numpy(), g_full.numpy(), rtol=1e-9, atol=1e-14)
+
+
+def test_chunked_oracle_helpers_match_the_oracle():
+    """tests/_helpers.py evaluates loss_fn / render over ray chunks at the BASELINE sizes; here it is checked against
+    the unchunked oracle (float64: identical up to summation order)."""
+    from _helpers import make_params, make_rays, oracle_loss_and_grad_chunked, oracle_render_chunked
+    cfg = O.Cfg(sparsity_npoints=64, weight_decay_mult=0.3)
+    flat = make_params(cfg, bias_scale=0.2).double()
+    B = 12
+    rays = O.Rays(*[x.double() for x in make_rays(B, 3)])
+    gen = torch.Generator().manual_seed(1)
+    px = torch.rand(B, 3, generator=gen, dtype=torch.float64)
+    t_rand = torch.rand(B, 64, generator=gen, dtype=torch.float64)
+    u = torch.rand(B, 128, generator=gen, dtype=torch.float64)
+    sp = (torch.rand(64, 3, generator=gen, dtype=torch.float64) * 2 - 1) * 1.5
+    _, st, g = O.loss_and_grad(flat, rays, px, cfg, t_rand, u, sp)
+    st_c, g_c = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp, torch.float64, chunk=5)
+    for k in st:
+        assert abs(float(st[k]) - st_c[k]) <= 1e-12 * max(1.0, abs(float(st[k]))), k
+    assert float((g - g_c).norm() / g.norm()) < 1e-12
+    with torch.no_grad():
+        ref = O.render(O.unflatten_params(flat, cfg), rays, cfg, t_rand, u)
+    got = oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float64, chunk=5)
+    for lvl in range(2):
+        for j in range(3):
+            assert torch.equal(ref[lvl][j], got[lvl][j])

@@ -117,7 +117,7 @@ def oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_points, dtyp
         tgt = cast(px[sl])
         terms = [((lvl[0] - tgt) ** 2).sum() for lvl in ret]
         (sum(terms) / (3.0 * B)).backward()
-        sse[0] += float(terms[-1]); sse[1] += float(terms[0]) if fine else 0.0
+        sse[0] += float(terms[-1].detach()); sse[1] += float(terms[0].detach()) if fine else 0.0
     params = O.unflatten_params(p, cfg)
     tail = torch.zeros((), dtype=dtype)
     loss_sp = 0.0
@@ -135,3 +135,51 @@ def oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_points, dtyp
     stats = dict(loss=loss, psnr=psnr(loss), loss_c=loss_c if fine else 0.0, loss_sp=loss_sp,
                  psnr_c=psnr(loss_c) if fine else 0.0, weight_l2=float(weight_l2))
     return stats, p.grad.detach()
+
+
+def hip_sample_positions(ops, pcfg, packed, rays_dev, t_rand_dev, u_dev):
+    """(z_coarse [B,Nc], z_fine [B,Nc+Nf]) exactly as the HIP path draws them: the same C-ABI kernels
+    pxo_train_fwd_bwd sequences (sample_along_rays -> mlp_fwd -> shade_composite_fwd -> sample_pdf)."""
+    o, d, v = rays_dev
+    z_c, pts = ops.sample_along_rays(o, d, pcfg.num_coarse_samples, pcfg.near_, pcfg.far_, t_rand_dev)
+    if pcfg.num_fine_samples == 0:
+        return z_c, None
+    raw_rgb, raw_sigma = ops.mlp_fwd(pcfg, packed[0][0], pts)
+    _, _, _, w = ops.shade_composite_fwd(pcfg, raw_rgb, raw_sigma, z_c, d, v)
+    z_f, _ = ops.sample_pdf(z_c, w, o, d, pcfg.num_fine_samples, u_dev)
+    return z_c, z_f
+
+
+def oracle_loss_and_grad_given_z(flat, rays, px, cfg, z_c, z_f, sp_points, dtype=torch.float64):
+    """loss_fn (nerf_sh/train.py:68-114) and its gradient with the SAMPLE POSITIONS given instead of drawn.
+
+    No gradient flows through the positions (lax.stop_gradient, nerf_sh/nerf/model_utils.py:286), so with z fixed
+    this is the same differentiable function as O.loss_fn -- minus the ill-conditioned inverse-CDF step, whose own
+    parity is tested through F(z) = u (test_sample_pdf) and through the rendered colours.  Composition follows
+    O.render / nerf_sh/nerf/models.py:216-348 (cast_rays -> MLP -> eval_sh/sigmoid/relu -> volumetric_rendering)."""
+    cast = lambda t: t.to(dtype)
+    p = flat.to(dtype).detach().clone().requires_grad_(True)
+    params = O.unflatten_params(p, cfg)
+    o, d, v = [cast(x) for x in rays]
+    tgt = cast(px)
+
+    def level(mlp, z):
+        z = cast(z)
+        rgb, sigma, _, _ = O._shade(mlp, O.cast_rays(z, o, d), v, cfg)
+        return O.volumetric_rendering(rgb, sigma, z, d, cfg.white_bkgd)[0]
+
+    fine = cfg.num_fine_samples > 0
+    rgb_c = level(params[0], z_c)
+    loss_c = ((rgb_c - tgt) ** 2).mean()
+    if fine:
+        loss = ((level(params[1], z_f) - tgt) ** 2).mean()
+    else:
+        loss, loss_c = loss_c, torch.zeros((), dtype=dtype)
+    total = loss + loss_c
+    if cfg.sparsity_weight > 0.0:
+        _, sig = O.eval_points_raw(params, cast(sp_points), cfg)
+        total = total + cfg.sparsity_weight * (1.0 - torch.exp(-cfg.sparsity_length * torch.relu(sig)).mean())
+    leaves = [t for mlp in params for pair in mlp for t in pair]
+    total = total + cfg.weight_decay_mult * (sum((z ** 2).sum() for z in leaves) / sum(z.numel() for z in leaves))
+    total.backward()
+    return float(loss), float(loss_c), p.grad.detach()

@@ -16,7 +16,8 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-from _helpers import _gpu, _ops, _psnr, close, make_params, make_rays, pxo_cfg, split_mlp  # noqa: E402
+from _helpers import (_gpu, _ops, _psnr, close, hip_sample_positions, make_params, make_rays,  # noqa: E402
+                      oracle_loss_and_grad_given_z, pxo_cfg, split_mlp)
 
 
 # ---------------------------------------------------------------------------------------
@@ -413,24 +414,32 @@ def test_train_fwd_bwd_matches_oracle(deg, Nf, sp):
     s = stats.cpu()
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
         close(f"stats/{k}", s[i], st[k].float(), rtol=2e-5, atol=1e-6)
-    # float64 oracle as the arbiter: the HIP gradient must be as close to it as the float32 CPU
-    # gradient is (both float32 paths may take a different ReLU branch for a pre-activation within
-    # round-off of 0, which moves a whole row's contribution; ~1e-4 relative per event).
-    d64 = lambda t: None if t is None else t.double()
-    r64 = O.Rays(*[x.double() for x in rays])
-    _, _, g64 = O.loss_and_grad(flat.double(), r64, px.double(), cfg, d64(t_rand), d64(u if Nf > 0 else None), d64(sp_pts))
+    # Gradient.  End to end (positions drawn by each path) the comparison is dominated by the inverse-CDF step: a
+    # fine sample that falls into a nearly empty bin moves by a fraction of a bin per ulp of the cdf, so at 48 rays
+    # two correct float32 evaluations can be several % away from float64 (that step has its own test: test_sample_pdf,
+    # F(z) = u, and the rendered colours).  The arbiter used here is therefore the float64 loss_fn evaluated AT THE
+    # HIP PATH'S OWN SAMPLE POSITIONS (no gradient flows through them, model_utils.py:286): everything downstream --
+    # posenc, both MLPs forward and backward, SH, compositing, the three loss terms -- is held to a fixed bound.
+    # What remains is float32 round-off and ReLU-kink branch differences (~1e-4 each).
+    rays_dev = (rays.origins.to(dev), rays.directions.to(dev), rays.viewdirs.to(dev))
+    z_c, z_f = hip_sample_positions(ops, pcfg, packed, rays_dev, t_rand.to(dev), u.to(dev))
+    l64, lc64, g64 = oracle_loss_and_grad_given_z(flat, rays, px, cfg, z_c.cpu(), None if z_f is None else z_f.cpu(),
+                                                  sp_pts)
+    close("loss vs f64 at the same positions", s[0], torch.tensor(l64), rtol=1e-5, atol=1e-7)
+    if Nf > 0:
+        close("loss_c vs f64 at the same positions", s[2], torch.tensor(lc64), rtol=1e-5, atol=1e-7)
     n = flat.numel() // 2
     halves = [(0, n)] + ([(n, 2 * n)] if Nf > 0 else [])
     for lo, hi in halves:
         ref = g64[lo:hi]
         assert float(ref.norm()) > 1e-4, "degenerate test: oracle gradient vanishes"
         e_hip = float((grads[lo:hi].cpu().double() - ref).norm() / ref.norm())
-        e_cpu = float((g_ref[lo:hi].double() - ref).norm() / ref.norm())
-        # fixed bound: at 48 rays a handful of ReLU-kink branch differences (~1e-4 each) is the whole error budget;
-        # the 4096-ray tests (tests/test_gpu_fullsize.py) hold 1e-3
-        assert e_hip <= 2e-3, f"MLP_{lo // n}: rel L2 err HIP {e_hip:.3g} (CPU-f32 {e_cpu:.3g})"
+        assert e_hip <= 1e-3, f"MLP_{lo // n}: rel L2 err vs the f64 oracle at the same sample positions {e_hip:.3g}"
     if Nf == 0:
         assert float(grads[n:].abs().max()) == 0.0
+    # end to end (each path draws its own positions): HIP float32 against the CPU float32 oracle
+    e_f32 = float((grads.cpu().double() - g_ref.double()).norm() / g_ref.double().norm())
+    assert e_f32 <= 2e-2, f"rel L2 err vs the float32 oracle, end to end: {e_f32:.3g}"
 
 
 def test_grid_sigma_matches_eval_points():
@@ -603,9 +612,10 @@ def test_trained_psnr_matches_oracle_training():
         p, m, v, _, _ = O.train_step(p, m, v, step, rays, batch["pixels"], cfg, t_rand, u, sp, lr)
         dbatch = {"rays": utils.Rays(*[r.to(dev) for r in batch["rays"]]), "pixels": batch["pixels"].to(dev)}
         models.train_step(model, state, dbatch, lr, t_rand=t_rand.to(dev), u=u.to(dev), sp_points=sp.to(dev))
-    test = datasets.get_dataset("test", args, torch.device("cpu")).get_image(0)
-    rays = O.Rays(*[r.reshape(-1, 3)[::3].contiguous() for r in test["rays"]])
-    px = test["pixels"].reshape(-1, 3)[::3]
+    test_ds = datasets.get_dataset("test", args, torch.device("cpu"))
+    views = [test_ds.get_image(i) for i in (0, 67, 133)]                 # three held-out views, every 4th pixel
+    rays = O.Rays(*[torch.cat([t["rays"][k].reshape(-1, 3)[::4] for t in views]).contiguous() for k in range(3)])
+    px = torch.cat([t["pixels"].reshape(-1, 3)[::4] for t in views])
     with torch.no_grad():
         ref = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
         init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]

@@ -167,7 +167,8 @@ def test_dp_invariance_of_mean_of_shard_means():
 def test_chunked_oracle_helpers_match_the_oracle():
     """tests/_helpers.py evaluates loss_fn / render over ray chunks at the BASELINE sizes; here it is checked against
     the unchunked oracle (float64: identical up to summation order)."""
-    from _helpers import make_params, make_rays, oracle_loss_and_grad_chunked, oracle_render_chunked
+    from _helpers import (make_params, make_rays, oracle_loss_and_grad_chunked, oracle_loss_and_grad_given_z,
+                          oracle_render_chunked)
     cfg = O.Cfg(sparsity_npoints=64, weight_decay_mult=0.3)
     flat = make_params(cfg, bias_scale=0.2).double()
     B = 12
@@ -183,7 +184,11 @@ def test_chunked_oracle_helpers_match_the_oracle():
         assert abs(float(st[k]) - st_c[k]) <= 1e-12 * max(1.0, abs(float(st[k]))), k
     assert float((g - g_c).norm() / g.norm()) < 1e-12
     with torch.no_grad():
-        ref = O.render(O.unflatten_params(flat, cfg), rays, cfg, t_rand, u)
+        ref, aux = O.render(O.unflatten_params(flat, cfg), rays, cfg, t_rand, u, return_aux=True)
+    # the loss with the sample positions injected (gradient arbiter of the GPU tests) is the same function
+    l, lc, g_z = oracle_loss_and_grad_given_z(flat, rays, px, cfg, aux["z_c"], aux["z_f"], sp, torch.float64)
+    assert abs(l - float(st["loss"])) < 1e-14 and abs(lc - float(st["loss_c"])) < 1e-14
+    assert float((g - g_z).norm() / g.norm()) < 1e-13
     got = oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float64, chunk=5)
     for lvl in range(2):
         for j in range(3):

@@ -87,14 +87,8 @@ def _build(force, verbose, extra_flags, objdir):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    if "--variants" in sys.argv:   # previous-generation inner loops, for in-session A/B runs
-        build(suffix="_g0", extra_flags=("-DPXO_GEOM=0",))      # 64-row tiles, two workgroups per CU
+    if "--variants" in sys.argv:   # A/B libraries for one GPU session (selected at run time with PXO_LIB)
+        build(suffix="_bd2", extra_flags=("-DPXO_BDIST=2",))     # weight fragments fetched 2 k-groups ahead (3 = default)
     if "--wgrad-variants" in sys.argv:
         for v in (1, 2, 3, 4):
             build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))
-    if "--trace" in sys.argv:      # cycle-stamped forward kernel (timing experiment)
-        build(suffix="_trace_g1", extra_flags=("-DPXO_TRACE", "-DPXO_GEOM=1"))
-        build(suffix="_trace_g0", extra_flags=("-DPXO_TRACE", "-DPXO_GEOM=0"))
-    if "--ablations" in sys.argv:  # timing-only experiments on the forward kernel (results are wrong)
-        for lvl in (1, 2, 3):
-            build(suffix=f"_abl{lvl}", extra_flags=(f"-DPXO_ABLATE={lvl}",))

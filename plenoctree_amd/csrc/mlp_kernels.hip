@@ -5,19 +5,21 @@
 // SH configuration (nerf_sh/config/blender.yaml, tt.yaml), plus its reverse-mode data path.
 //
 // Design (exact f32, v_mfma_f32_32x32x2_f32):
-//  * persistent workgroups (two per CU, 4 waves each) walk 64-sample tiles; the 64x256 activation
-//    tile lives in LDS (row stride 260 floats: conflict-free ds_read_b128 A-fragments) for all 8
-//    layers and is updated in place.  Two independent workgroups per CU mean one's epilogue /
-//    barriers overlap the other's MFMAs on the same SIMDs;
-//  * weights are pre-packed in MFMA fragment order (pxo_common.h packed_index) so the B operand
-//    is one coalesced 16 B/lane load straight from L2 into registers -- each wave owns a
-//    disjoint 64-column slice of the layer, so weights need no LDS staging at all;
+//  * one persistent 8-wave workgroup per CU (two waves per SIMD) walks 128-row tiles (pxo_common.h TileSched:
+//    whole rounds of full tiles, then one round of 64-row half tiles for a ragged remainder); the 128x256
+//    activation tile lives in LDS (row stride 260 floats: conflict-free ds_read_b128 A-fragments) for all 8
+//    layers and is updated in place;
+//  * every wave owns all 128 rows x 32 columns of a layer (4 accumulator tiles): one weight-fragment load
+//    feeds 16 MFMAs.  Weights are pre-packed in MFMA fragment order (pxo_common.h packed_index) so the B
+//    operand is one coalesced 16 B/lane load straight from L2 into registers -- the waves' column slices are
+//    disjoint, so weights need no LDS staging at all; B is fetched three k-groups ahead through four rotating
+//    register sets, A (LDS) one group ahead;
 //  * the K order inside a dot product is permuted (lane half h, sub-step j -> k = 8g+4h+j) so
 //    that one ds_read_b128 / one 16 B global load feeds four consecutive MFMAs;
 //  * post-ReLU activations are streamed to HBM once (for the weight-gradient GEMMs) as whole
 //    1 KiB rows copied out of the LDS tile, together with a 1-bit relu mask in fragment order, so
-//    the backward-data kernel never re-reads them; bias gradients accumulate in registers across
-//    a workgroup's tiles.
+//    the backward-data kernel never re-reads them; bias gradients accumulate in LDS across a
+//    workgroup's tiles (one owner thread per element) and leave as one partial per workgroup.
 #include "pxo_common.h"
 
 namespace pxo {
@@ -148,12 +150,14 @@ __device__ __forceinline__ void grid_point(const GridSpec& g, int64_t n, float& 
   pz = ((((float)iz + 0.5f) / (float)r) - g.off[2]) / g.scale[2];
 }
 
-// writes posenc of the tile's kTM points into lds[:, 0:64]
+// writes posenc of the tile's 32*RBN points into lds[:, 0:64]
+template <int RBN>
 __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float* __restrict__ pts,
                                             const GridSpec& grid, int64_t row0, int64_t M, int tid) {
-  constexpr int kParts = kMlpThreads / kTM;       // 4
-  constexpr int kColsPer = kEncPad / kParts;      // 16
-  const int row = tid % kTM, part = tid / kTM;
+  constexpr int kRows = 32 * RBN;
+  constexpr int kParts = kMlpThreads / kRows;     // 4 (full tile) / 8 (half tile)
+  constexpr int kColsPer = kEncPad / kParts;      // 16 / 8
+  const int row = tid % kRows, part = tid / kRows;
   const int64_t grow = row0 + row;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
   if (grow < M) {
@@ -193,59 +197,46 @@ __device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int 
   for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
 }
 
-// B (weights, L2 latency) is fetched two k-groups ahead into four rotating register sets, A (LDS)
+// B (weights, L2 latency) is fetched PXO_BDIST k-groups ahead into four rotating register sets, A (LDS)
 // one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
 // sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
 // each load to just before its use and exposes the LDS/L2 latency on every k-group.
+#ifndef PXO_BDIST
+#define PXO_BDIST 3      // k-groups of look-ahead for the weight fragments (2 or 3; four register sets either way)
+#endif
 #define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
-  f32x4 a0[RBN], a1[RBN], b0[CBN], b1[CBN], b2[CBN], b3[CBN];
+  constexpr int D = PXO_BDIST;
+  static_assert(D == 2 || D == 3, "PXO_BDIST");
+  f32x4 a0[RBN], a1[RBN], b[4][CBN];
   const int last = kgroups - 1;
   auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
-  load_b<CBN>(wp, 0, kg_stride, b0);
-  load_b<CBN>(wp, 1, kg_stride, b1);
-#if PXO_BDIST == 3
-  load_b<CBN>(wp, cl(2), kg_stride, b2);
-#endif
+#pragma unroll
+  for (int i = 0; i < D; ++i) load_b<CBN>(wp, cl(i), kg_stride, b[i]);
   load_a<RBN>(arow, 0, a0);
   for (int g = 0; g < kgroups; g += 4) {
+    // phase p multiplies k-group g+p out of set p and refills set (p+D)%4 with k-group g+p+D
     load_a<RBN>(arow, g + 1, a1);
-#if PXO_BDIST == 3
-    load_b<CBN>(wp, cl(g + 3), kg_stride, b3);
-#else
-    load_b<CBN>(wp, g + 2, kg_stride, b2);
-#endif
+    load_b<CBN>(wp, cl(g + D), kg_stride, b[D & 3]);
     PXO_PIN();
-    mfma_group<RBN, CBN>(a0, b0, acc);
+    mfma_group<RBN, CBN>(a0, b[0], acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 2, a0);
-#if PXO_BDIST == 3
-    load_b<CBN>(wp, cl(g + 4), kg_stride, b0);
-#else
-    load_b<CBN>(wp, g + 3, kg_stride, b3);
-#endif
+    load_b<CBN>(wp, cl(g + 1 + D), kg_stride, b[(1 + D) & 3]);
     PXO_PIN();
-    mfma_group<RBN, CBN>(a1, b1, acc);
+    mfma_group<RBN, CBN>(a1, b[1], acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 3, a1);
-#if PXO_BDIST == 3
-    load_b<CBN>(wp, cl(g + 5), kg_stride, b1);
-#else
-    load_b<CBN>(wp, cl(g + 4), kg_stride, b0);
-#endif
+    load_b<CBN>(wp, cl(g + 2 + D), kg_stride, b[(2 + D) & 3]);
     PXO_PIN();
-    mfma_group<RBN, CBN>(a0, b2, acc);
+    mfma_group<RBN, CBN>(a0, b[2], acc);
     PXO_PIN();
     load_a<RBN>(arow, cl(g + 4), a0);
-#if PXO_BDIST == 3
-    load_b<CBN>(wp, cl(g + 6), kg_stride, b2);
-#else
-    load_b<CBN>(wp, cl(g + 5), kg_stride, b1);
-#endif
+    load_b<CBN>(wp, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);
     PXO_PIN();
-    mfma_group<RBN, CBN>(a1, b3, acc);
+    mfma_group<RBN, CBN>(a1, b[3], acc);
     PXO_PIN();
   }
 }
@@ -286,13 +277,14 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {
 // accumulator register `reg` of a 32x32 tile holds row (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// coalesced copy of the finished kTM x 256 LDS tile to a row-major [M,256] global array (whole 1 KiB
+// coalesced copy of the finished (32*RBN) x 256 LDS tile to a row-major [M,256] global array (whole 1 KiB
 // rows per wave instruction).  Tried and measured no better: only half of the waves copying while the
 // others start the next GEMM, non-temporal stores, and trickling the copy through the next GEMM.
+template <int RBN>
 __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
                                            int64_t M, bool full, int tid) {
 #pragma unroll
-  for (int i = 0; i < kTM * kW / 4 / kMlpThreads; ++i) {
+  for (int i = 0; i < 32 * RBN * kW / 4 / kMlpThreads; ++i) {
     const int idx = tid + kMlpThreads * i;
     const int row = idx >> 6, c4 = idx & 63;
     if (full || row0 + row < M)
@@ -301,165 +293,142 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
   }
 }
 
-constexpr int kRB = kTM / 32;                    // row blocks per tile (all owned by every wave)
-constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 256-wide layer
-
-#ifdef PXO_TRACE
-// cycle stamps of wave 0 of workgroup 0 over its first two tiles (timing experiments only)
-__device__ unsigned long long g_trace[512];
-__device__ int g_trace_n;
-#define TRACE(id)                                                                     \
-  do {                                                                                \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && tile >= 10 * (int64_t)gridDim.x && tile < 12 * (int64_t)gridDim.x && g_trace_n < 510) { \
-      g_trace[g_trace_n] = ((unsigned long long)(id) << 48) | (clock64() & 0xFFFFFFFFFFFFull); \
-      g_trace_n++;                                                                    \
-    }                                                                                 \
-  } while (0)
-#else
-#define TRACE(id)
-#endif
+constexpr int kRB = kTM / 32;                    // row blocks of a full tile (all owned by every wave)
+constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 256-wide layer (1)
 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int NHB, bool SAVE>
+// One tile of 32*RBN rows starting at row0 (RBN = 4: full tile, RBN = 2: half-height tail tile, see
+// pxo_common.h TileSched) through posenc, the 8 trunk layers and the heads.  RGB = false computes only the
+// head block that holds the sigma column (octree/extraction.py:316-317 and the sparsity branch of
+// nerf_sh/train.py:80-81 discard raw_rgb).
+template <int NHB, bool SAVE, bool RGB, int RBN>
+__device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* __restrict__ pk,
+                                         const float* __restrict__ pts, const GridSpec& grid, int64_t M, int deg,
+                                         int64_t row0, int64_t slot, float* __restrict__ raw_rgb,
+                                         float* __restrict__ raw_sigma, float* __restrict__ acts,
+                                         float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,
+                                         int wave) {
+  constexpr int kRows = 32 * RBN;
+  constexpr int kWordsUsed = RBN * kCB * 16 / 32;     // relu-mask words this tile height fills (of kMaskWords)
+  const int C = rgb_channels(deg);
+  const float* __restrict__ bias = pk + fwd_bias_off(deg);
+  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
+  const bool full = row0 + kRows <= M;
+  __syncthreads();   // previous tile's head GEMM has consumed the LDS tile
+  posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+  __syncthreads();
+  if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
+#pragma unroll
+    for (int i = 0; i < kRows * kEncPad / 4 / kMlpThreads; ++i) {
+      const int idx = tid + kMlpThreads * i;
+      const int row = idx >> 4, c4 = idx & 15;
+      if (full || row0 + row < M)
+        *reinterpret_cast<f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+    }
+  }
+
+  f32x16 acc[RBN][kCB];
+  for (int l = 0; l < kDepth; ++l) {
+    zero_acc(acc);
+    float bl[kCB];                       // this layer's biases, fetched under the GEMM
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
+    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
+    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+    if (l == 5) {
+      // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
+      // columns are a second K segment; the encoding is recomputed into the consumed tile.
+      __syncthreads();
+      posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+      __syncthreads();
+      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
+    }
+    __syncthreads();  // every wave has consumed the input tile
+    // re-derive the lane ids from an opaque copy so that the epilogue / store addresses are
+    // computed here instead of being hoisted out of the loops into (scarce) registers
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
+    uint32_t mw[kMaskWords];
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) mw[w] = 0u;
+#pragma unroll
+    for (int r = 0; r < RBN; ++r)
+#pragma unroll
+      for (int c = 0; c < kCB; ++c) {
+        const int col = (wave * kCB + c) * 32 + (lane_e & 31);
+        const float b = bl[c];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = r * 32 + frag_row(reg, lane_e);
+          const float v = fmaxf(acc[r][c][reg] + b, 0.f);
+          lds[row * kLDA + col] = v;
+          if (SAVE) {
+            const int bit = (r * kCB + c) * 16 + reg;
+            if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
+          }
+        }
+      }
+    if (SAVE) {
+      uint32_t* mp = mask + ((slot * kDepth + l) * kMlpThreads + tid_e) * kMaskWords;
+#pragma unroll
+      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];
+    }
+    __syncthreads();
+    if (SAVE) store_tile<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
+  }
+
+  // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
+  // wave w owns row block w % RBN and the column blocks w / RBN, w / RBN + CSTEP, ... -- one 32x32
+  // accumulator at a time (two at once, as SH25's three blocks over two waves would need, spill the
+  // 256-VGPR budget of this kernel)
+  {
+    constexpr int CSTEP = kMlpWaves / RBN;               // waves sharing a row block
+    constexpr int HMAX = RGB ? (NHB + CSTEP - 1) / CSTEP : 1;
+    const int rb = wave % RBN, cb0 = wave / RBN;
+    const float* ar = arow + rb * 32 * kLDA;
+    const float* hb = bias + 8 * kW;
+#pragma unroll 1
+    for (int i = 0; i < HMAX; ++i) {
+      // sigma-only: the last block holds column C (Dense_8); one wave per row block computes it
+      const int cb = RGB ? cb0 + i * CSTEP : (cb0 == 0 ? NHB - 1 : NHB);
+      if (cb >= NHB) continue;                             // wave-uniform
+      f32x16 hacc[1][1];
+      zero_acc(hacc);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + cb * 64 + lane;
+      gemm_head<1>(ar, wp, 0, NHB * 64, hacc);
+      const int col = cb * 32 + (lane & 31);
+      const float b = hb[col];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
+        if (grow < M) {
+          const float v = hacc[0][0][reg] + b;
+          if (col < C) { if (RGB) raw_rgb[grow * C + col] = v; }
+          else if (col == C) raw_sigma[grow] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NHB, bool SAVE, bool RGB>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_fwd_kernel(
-    const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg,
+    const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg, TileSched ts,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma, float* __restrict__ acts,
     float* __restrict__ enc_out, uint32_t* __restrict__ mask) {
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int C = rgb_channels(deg);
-  const float* __restrict__ bias = pk + fwd_bias_off(deg);
-  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  const int64_t ntiles = num_tiles(M);
-
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * kTM;
-    const bool full = row0 + kTM <= M;
-    __syncthreads();   // previous tile's head GEMM has consumed the LDS tile
-    TRACE(1);
-    posenc_tile(lds, pts, grid, row0, M, tid);
-    __syncthreads();
-    TRACE(2);
-    if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
-#pragma unroll
-      for (int i = 0; i < kTM * kEncPad / 4 / kMlpThreads; ++i) {
-        const int idx = tid + kMlpThreads * i;
-        const int row = idx >> 4, c4 = idx & 15;
-        if (full || row0 + row < M)
-          *reinterpret_cast<f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4) =
-              *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
-      }
-    }
-
-    f32x16 acc[kRB][kCB];
-    for (int l = 0; l < kDepth; ++l) {
-      zero_acc(acc);
-      float bl[kCB];                       // this layer's biases, fetched under the GEMM
-#pragma unroll
-      for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
-      TRACE(10 + l);
-      gemm_lds_packed<kRB, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
-      TRACE(20 + l);
-      if (l == 5) {
-        // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
-        // columns are a second K segment; the encoding is recomputed into the consumed tile.
-        __syncthreads();
-#if !defined(PXO_ABLATE) || PXO_ABLATE < 2
-        posenc_tile(lds, pts, grid, row0, M, tid);
-#endif
-        __syncthreads();
-        gemm_lds_packed<kRB, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
-      }
-#if defined(PXO_ABLATE) && PXO_ABLATE >= 3
-#pragma unroll
-      for (int r = 0; r < kRB; ++r)
-#pragma unroll
-        for (int c = 0; c < kCB; ++c) asm volatile("" ::"v"(acc[r][c]));
-      continue;
-#endif
-      TRACE(30 + l);
-      __syncthreads();  // every wave has consumed the input tile
-      TRACE(40 + l);
-      // re-derive the lane ids from an opaque copy so that the epilogue / store addresses are
-      // computed here instead of being hoisted out of the loops into (scarce) registers
-      int tid_e = tid;
-      asm volatile("" : "+v"(tid_e));
-      const int lane_e = tid_e & 63;
-      uint32_t mw[kMaskWords];
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) mw[w] = 0u;
-#pragma unroll
-      for (int r = 0; r < kRB; ++r)
-#pragma unroll
-        for (int c = 0; c < kCB; ++c) {
-          const int col = (wave * kCB + c) * 32 + (lane_e & 31);
-          const float b = bl[c];
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int row = r * 32 + frag_row(reg, lane_e);
-            const float v = fmaxf(acc[r][c][reg] + b, 0.f);
-            lds[row * kLDA + col] = v;
-            if (SAVE) {
-              const int bit = (r * kCB + c) * 16 + reg;
-              if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
-            }
-          }
-        }
-#if !defined(PXO_ABLATE)
-      if (SAVE) {
-        uint32_t* mp = mask + ((tile * kDepth + l) * kMlpThreads + tid_e) * kMaskWords;
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) mp[w] = mw[w];
-      }
-#else
-      asm volatile("" ::"v"(mw[0]), "v"(mw[kMaskWords - 1]));
-#endif
-      TRACE(50 + l);
-      __syncthreads();
-      TRACE(60 + l);
-      if (SAVE) store_tile(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
-      TRACE(70 + l);
-    }
-
-    // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
-    // wave w owns row block w % kRB and the column blocks w / kRB, w / kRB + CSTEP, ...
-    {
-      constexpr int CSTEP = kMlpWaves / kRB;               // waves sharing a row block
-      constexpr int HMAX = (NHB + CSTEP - 1) / CSTEP;
-      const int rb = wave % kRB, cb0 = wave / kRB;
-      f32x16 hacc[1][HMAX];
-      zero_acc(hacc);
-      // column blocks cb0, cb0+CSTEP, ...; a block past NHB is clamped (computed twice, stored once)
-      const int cbl = cb0 + (HMAX - 1) * CSTEP < NHB ? CSTEP : 0;
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + cb0 * 64 + lane;
-      const float* ar = arow + rb * 32 * kLDA;
-      // same pipelined loop as the trunk (CBN column blocks `cbl*64` f32x4 apart)
-      gemm_head<HMAX>(ar, wp, cbl * 64, NHB * 64, hacc);
-      TRACE(90);
-      const float* hb = bias + 8 * kW;
-#pragma unroll
-      for (int i = 0; i < HMAX; ++i) {
-        const int cb = cb0 + i * CSTEP;
-        if (cb < NHB) {
-          const int col = cb * 32 + (lane & 31);
-          const float b = hb[col];
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
-            if (grow < M) {
-              const float v = hacc[0][i][reg] + b;
-              if (col < C) { if (raw_rgb) raw_rgb[grow * C + col] = v; }
-              else if (col == C) raw_sigma[grow] = v;
-            }
-          }
-        }
-      }
-    }
-  }
+  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)
+    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,
+                                  mask, tid, lane, wave);
+  for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
+    fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + h * (kTM / 2), ts.n_full + h,
+                                      raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);
 }
 
 static unsigned mlp_grid(int64_t M) {
@@ -473,11 +442,18 @@ static int launch_fwd_nhb(const PxoCfg* cfg, const float* pk, const float* pts, 
                           uint32_t* mask, hipStream_t s) {
   KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
-  if (acts)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
+  const TileSched ts = tile_sched(M, grid_dim.x);
+  if (acts && raw_rgb)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
+                       raw_rgb, raw_sigma, acts, enc, mask);
+  else if (acts)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
+                       raw_rgb, raw_sigma, acts, enc, mask);
+  else if (raw_rgb)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
                        raw_rgb, raw_sigma, acts, enc, mask);
   else
-    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg,
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
                        raw_rgb, raw_sigma, acts, enc, mask);
   return check_launch("mlp_fwd");
 }
@@ -514,92 +490,102 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // ------------------------------------------------------------------------------------------
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
+template <int NHB, int RBN>
+__device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restrict__ my_db,
+                                         const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
+                                         const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask,
+                                         int64_t M, int deg, int64_t row0, int64_t slot, float* __restrict__ dz,
+                                         int tid, int lane, int wave) {
+  constexpr int NH = 32 * NHB;
+  constexpr int kRows = 32 * RBN;
+  constexpr int kWordsUsed = RBN * kCB * 16 / 32;
+  const int C = rgb_channels(deg);
+  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
+  const bool full = row0 + kRows <= M;
+  __syncthreads();   // previous tile's stores out of LDS are done
+  // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
+  for (int idx = tid; idx < kRows * NH; idx += kMlpThreads) {
+    const int row = idx / NH, col = idx - row * NH;
+    const int64_t grow = row0 + row;
+    float v = 0.f;
+    if (grow < M) {
+      if (col < C) { if (d_raw_rgb) v = d_raw_rgb[grow * C + col]; }
+      else if (col == C) v = d_raw_sigma[grow];
+    }
+    lds[row * kLDA + col] = v;
+  }
+  __syncthreads();
+  if (tid < NH) {  // head bias gradient
+    float sum = 0.f;
+#pragma unroll 8
+    for (int row = 0; row < kRows; ++row) sum += lds[row * kLDA + tid];
+    my_db[8 * kW + tid] += sum;
+  }
+
+  f32x16 acc[RBN][kCB];
+  zero_acc(acc);
+  uint32_t mw[kMaskWords];   // relu-mask words of the layer whose gradient the running GEMM produces
+  {
+    const uint32_t* mp = mask + ((slot * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords;
+#pragma unroll
+    for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];
+    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
+    gemm_lds_packed<RBN, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
+  }
+  for (int l = kDepth - 1; l >= 0; --l) {
+    __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));   // see fwd_tile: keeps the epilogue addresses out of the loops' live set
+    const int lane_e = tid_e & 63;
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) {
+      const int col = (wave * kCB + c) * 32 + (lane_e & 31);
+      float colsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < RBN; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = r * 32 + frag_row(reg, lane_e);
+          const int bit = (r * kCB + c) * 16 + reg;
+          const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
+          lds[row * kLDA + col] = v;
+          colsum += v;
+        }
+      colsum += __shfl_xor(colsum, 32);
+      if (lane_e < 32) my_db[l * kW + col] += colsum;
+    }
+    __syncthreads();
+    if (l > 0) {
+      zero_acc(acc);
+      const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
+#pragma unroll
+      for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
+      store_tile<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
+      gemm_lds_packed<RBN, kCB>(arow, wp, 32, 8 * 64, acc);
+    } else {
+      store_tile<RBN>(lds, dz, row0, M, full, tid_e);
+    }
+  }
+}
+
 template <int NHB>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
-    const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg,
+    const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg, TileSched ts,
     float* __restrict__ dz, float* __restrict__ dbias_partial) {
   // activation-gradient tile + this workgroup's bias-gradient accumulators [9][256] (each element is
   // read-modify-written by one fixed thread; kept in LDS so the epilogue never waits on memory)
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + 9 * kW];
   float* __restrict__ my_db = lds + kTM * kLDA;
-  constexpr int NH = 32 * NHB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int C = rgb_channels(deg);
-  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
-  const int64_t ntiles = num_tiles(M);
   for (int i = tid; i < 9 * kW; i += kMlpThreads) my_db[i] = 0.f;
-
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * kTM;
-    const bool full = row0 + kTM <= M;
-    __syncthreads();   // previous tile's stores out of LDS are done
-    // d_raw tile -> lds[:, 0:NH] with the head's column order
-    for (int idx = tid; idx < kTM * NH; idx += kMlpThreads) {
-      const int row = idx / NH, col = idx - row * NH;
-      const int64_t grow = row0 + row;
-      float v = 0.f;
-      if (grow < M) {
-        if (col < C) v = d_raw_rgb[grow * C + col];
-        else if (col == C) v = d_raw_sigma[grow];
-      }
-      lds[row * kLDA + col] = v;
-    }
-    __syncthreads();
-    if (tid < NH) {  // head bias gradient
-      float sum = 0.f;
-#pragma unroll 8
-      for (int row = 0; row < kTM; ++row) sum += lds[row * kLDA + tid];
-      my_db[8 * kW + tid] += sum;
-    }
-
-    f32x16 acc[kRB][kCB];
-    zero_acc(acc);
-    uint32_t mw[kMaskWords];   // relu-mask words of the layer whose gradient the running GEMM produces
-    {
-      const uint32_t* mp = mask + ((tile * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords;
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
-      gemm_lds_packed<kRB, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
-    }
-    for (int l = kDepth - 1; l >= 0; --l) {
-      __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
-      int tid_e = tid;
-      asm volatile("" : "+v"(tid_e));   // see mlp_fwd_kernel: keeps the epilogue addresses out of the loops' live set
-      const int lane_e = tid_e & 63;
-#pragma unroll
-      for (int c = 0; c < kCB; ++c) {
-        const int col = (wave * kCB + c) * 32 + (lane_e & 31);
-        float colsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < kRB; ++r)
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int row = r * 32 + frag_row(reg, lane_e);
-            const int bit = (r * kCB + c) * 16 + reg;
-            const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
-            lds[row * kLDA + col] = v;
-            colsum += v;
-          }
-        colsum += __shfl_xor(colsum, 32);
-        if (lane_e < 32) my_db[l * kW + col] += colsum;
-      }
-      __syncthreads();
-      if (l > 0) {
-        zero_acc(acc);
-        const uint32_t* mp = mask + ((tile * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
-        const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
-        store_tile(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
-        gemm_lds_packed<kRB, kCB>(arow, wp, 32, 8 * 64, acc);
-      } else {
-        store_tile(lds, dz, row0, M, full, tid_e);
-      }
-    }
-  }
+  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)
+    bwd_tile<NHB, kRB>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, tile * kTM, tile, dz, tid, lane, wave);
+  for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
+    bwd_tile<NHB, kRB / 2>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, ts.half_row0 + h * (kTM / 2),
+                           ts.n_full + h, dz, tid, lane, wave);
   __syncthreads();
   // one partial per workgroup: [wg][9][256]
   float* out = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
@@ -614,33 +600,22 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
   if (M == 0) return PXO_OK;
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
+  const TileSched ts = tile_sched(M, grid_dim.x);
   switch (head_blocks(cfg->sh_deg)) {
     case 1:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
       break;
     case 2:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<2>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
       break;
     default:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<3>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
       break;
   }
   return check_launch("mlp_bwd_data");
 }
-
-#ifdef PXO_TRACE
-extern "C" int pxo_debug_trace(unsigned long long* out, int cap, int reset) {
-  int n = 0;
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(int));
-  if (n > cap) n = cap;
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n);
-  if (reset) { int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &z, sizeof(int)); }
-  return n;
-}
-#endif
 
 }  // namespace pxo

@@ -14,23 +14,12 @@ constexpr int kW = PXO_NET_WIDTH;        // 256
 constexpr int kDepth = PXO_NET_DEPTH;    // 8
 constexpr int kEnc = PXO_ENC_DIM;        // 63
 constexpr int kEncPad = PXO_ENC_PAD;     // 64
-// Geometry of the fused MLP kernels (build-time):
-//   PXO_GEOM 0: 64-row tiles, 4 waves (64 rows x 64 cols each), two independent workgroups per CU
-//   PXO_GEOM 1: 128-row tiles, 8 waves (128 rows x 32 cols each), one workgroup per CU -- half the
-//               weight-fragment loads per MFMA (scripts/ubench/gemm_geom.hip: 149.7 vs 138.3 TFLOP/s
-//               for the bare GEMM loop)
-#ifndef PXO_GEOM
-#define PXO_GEOM 1
-#endif
-#if PXO_GEOM == 0
-constexpr int kTM = 64;
-constexpr int kMlpThreads = 256;
-constexpr int kMlpWgPerCu = 2;
-#else
+// Geometry of the fused MLP kernels: 128-row tiles, 8 waves (every wave owns all rows x 32 columns of a layer),
+// one persistent workgroup per CU.  One weight-fragment load then feeds 16 MFMAs (scripts/ubench/gemm_geom.hip:
+// 149.7 TFLOP/s for the bare loop against 138.3 for 64 x 64 per wave).
 constexpr int kTM = 128;
 constexpr int kMlpThreads = 512;
 constexpr int kMlpWgPerCu = 1;
-#endif
 constexpr int kLDA = 260;                // LDS row stride (floats): 256 + one b128 access of pad
 constexpr int kMlpWaves = kMlpThreads / 64;
 constexpr int kMaskWords = (kTM / 32) * (8 / kMlpWaves) * 16 / 32;  // relu-mask words per thread per layer
@@ -91,10 +80,37 @@ __host__ __device__ inline int64_t bwd_layer_off(int l, int deg) {  // l in 1..7
 }
 __host__ __device__ inline int64_t bwd_image_floats(int deg) { return bwd_layer_off(0, deg); }
 
-// relu-mask image written by the forward kernel: per (tile, layer, thread) kMaskWords words
 __host__ __device__ inline int64_t num_tiles(int64_t M) { return (M + kTM - 1) / kTM; }
+
+// Tile schedule of one fused-MLP launch over M rows on `grid` persistent workgroups (the same function of (M, grid)
+// in the forward and the backward(data) kernel): whole rounds of full 128-row tiles; if the rows that are left fit
+// into ONE round at half height they are cut into 64-row tiles (one per workgroup, 2 of the 4 row blocks), so the
+// ragged last round costs about half a tile time instead of a whole one (4096 rays x 192 samples + 10,000 sparsity
+// points = 24 full rounds + 157 half tiles on 256 CUs, instead of 25 rounds).  Tile t lives in mask/partial slot t;
+// half tile h in slot n_full + h.
+struct TileSched {
+  int64_t n_full;      // full tiles: rows [t*128, t*128+128)
+  int64_t n_half;      // half tiles: rows [half_row0 + h*64, +64)
+  int64_t half_row0;
+};
+__host__ __device__ inline TileSched tile_sched(int64_t M, int64_t grid) {
+  TileSched t;
+  const int64_t tiles = num_tiles(M);
+  t.n_full = tiles; t.n_half = 0; t.half_row0 = tiles * kTM;
+  if (grid < 1 || tiles <= grid) return t;
+  const int64_t whole = (tiles / grid) * grid;
+  const int64_t left = M - whole * kTM;             // > 0 rows after the whole rounds (0 if tiles % grid == 0 and M % 128 == 0)
+  if (left > 0 && left <= grid * (kTM / 2)) {
+    t.n_full = whole;
+    t.half_row0 = whole * kTM;
+    t.n_half = (left + kTM / 2 - 1) / (kTM / 2);
+  }
+  return t;
+}
+// relu-mask image written by the forward kernel: per (slot, layer, thread) kMaskWords words
+__host__ __device__ inline int64_t mask_slots(int64_t M) { return num_tiles(M) + kMaxMlpGrid / 2; }
 __host__ __device__ inline int64_t mask_words(int64_t M) {
-  return num_tiles(M) * kDepth * kMlpThreads * kMaskWords;
+  return mask_slots(M) * kDepth * kMlpThreads * kMaskWords;
 }
 // bias-gradient partials written by the backward-data kernel, one per persistent workgroup: [wg][9][256]
 __host__ __device__ inline int64_t dbias_floats(int64_t M) { (void)M; return (int64_t)kMaxMlpGrid * 9 * kW; }

@@ -12,15 +12,21 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
+#ifndef PXO_WGRAD_SMALL
+#define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
+#endif
 
 // Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over
 // NSPLIT workgroups (each owns NOUT/NSPLIT output columns and re-reads X; the NSPLIT partners of a
 // row range are placed 8 blocks apart = on the same XCD so the second read of X hits L2).
-template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT>
+// DUAL: the NOUT = 512 columns are two row-major [M,256] arrays side by side (dZ | dZ2): Dense_0 and the skip rows of
+// Dense_5 share X = enc (model_utils.py:70-71), so one pass over enc produces both gradients.
+template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false>
 __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
-    int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab) {
+    int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr) {
   static_assert(WR * WC * 64 == NT, "wave grid");
+  static_assert(!DUAL || (NOUT == 2 * kW && NSPLIT == 1 && !HEAD), "dual source: two 256-wide arrays, no split");
   constexpr int NTILE = NOUT / NSPLIT;
   constexpr int RB = KIN / 32 / WR, CB = NTILE / 32 / WC;
   constexpr int XV = KCH * KIN / 4 / NT;                      // float4 per thread per X chunk
@@ -86,7 +92,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
         const int64_t grow = r0 + row;
         const bool ok = grow < r_end;
         okz |= (ok ? 1u : 0u) << i;
-        zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
+        if (DUAL) {
+          const float* __restrict__ src = c4 * 4 < kW ? dZ : dZ2;
+          zr4[i] = *reinterpret_cast<const f32x4*>(src + (ok ? grow : r_begin) * kW + ((c4 * 4) & (kW - 1)));
+        } else {
+          zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
+        }
       }
     }
   };
@@ -176,9 +187,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 // Block = 64 float4 columns x 4 partial groups: thread (q, v) adds slabs p = q, q+4, ... for the
 // float4 at element 4*(64*blockIdx.x + v); the four partial sums are combined through LDS in a
 // fixed order (deterministic).  16 B loads, P/4 of them per thread.
+// A second destination (dst2: columns [col0_2, col0_2+ncols) of the same rows) lets one pass over the slabs feed two
+// parameter leaves (the dual-source kernel above).
 __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
                                                           int rows_valid, int col0, int ncols,
-                                                          float* __restrict__ dst, int dst_ld) {
+                                                          float* __restrict__ dst, int dst_ld,
+                                                          float* __restrict__ dst2, int col0_2) {
   __shared__ f32x4 red[4][64];
   const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e4 = (int64_t)blockIdx.x * 64 + v;            // float4 index inside one slab
@@ -201,6 +215,7 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + j;
         if (n >= col0 && n < col0 + ncols) dst[(int64_t)i * dst_ld + (n - col0)] = t[j];
+        else if (dst2 && n >= col0_2 && n < col0_2 + ncols) dst2[(int64_t)i * dst_ld + (n - col0_2)] = t[j];
       }
     }
   }
@@ -232,8 +247,7 @@ __global__ void reduce_dbias_kernel(const float* __restrict__ partial, int64_t n
   }
 }
 
-static void split_rows(int64_t M, int64_t* rows_per_wg, int* P) {
-  int64_t target = num_cus();
+static void split_rows(int64_t M, int64_t target, int64_t* rows_per_wg, int* P) {
   int64_t rpw = (M + target - 1) / target;
   rpw = (rpw + kKC - 1) / kKC * kKC;
   if (rpw < kKC) rpw = kKC;
@@ -242,8 +256,9 @@ static void split_rows(int64_t M, int64_t* rows_per_wg, int* P) {
 }
 
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
-  // one KIN x NOUT (<= 256x256) slab per workgroup; split_rows never makes more than num_cus()
-  // workgroups, so the size does not depend on M (two passes of different M share one workspace)
+  // one KIN x NOUT slab per workgroup: 256 x 256 for up to num_cus() row ranges, or 64 x 512 / 256 x 96 for up to
+  // 2 num_cus() (the skinny products run two workgroups per CU); the size does not depend on M (two passes of
+  // different M share one workspace)
   (void)cfg; (void)M;
   return (size_t)num_cus() * kW * kW * sizeof(float);
 }
@@ -251,8 +266,15 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
 template <int NHB>
 static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const float* d_raw_sigma, int C,
                               int64_t M, int64_t rpw, int P, float* slab, hipStream_t s) {
+#if PXO_WGRAD_SMALL == 0
   hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 8, 1, true, 512, 32, 1>), dim3(P), dim3(512), 0, s, X, d_raw_rgb,
                      d_raw_sigma, C, M, rpw, P, slab);
+#else
+  // 4 waves, each 64 rows x all head columns (4 LDS operand reads per 4 MFMAs instead of 3 per 2), 40 KB of LDS:
+  // several workgroups per CU
+  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
+                     d_raw_sigma, C, M, rpw, P, slab);
+#endif
 }
 
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
@@ -263,22 +285,43 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   const int deg = cfg->sh_deg;
   const int C = rgb_channels(deg);
   int64_t rpw; int P;
-  split_rows(M, &rpw, &P);
-  if (ws_bytes < (size_t)P * kW * kW * sizeof(float)) {
+  split_rows(M, num_cus(), &rpw, &P);
+  int64_t rpw2; int P2;                      // the skinny products: two workgroups per CU
+#if PXO_WGRAD_SMALL == 0
+  split_rows(M, num_cus(), &rpw2, &P2);
+#else
+  split_rows(M, 2 * (int64_t)num_cus(), &rpw2, &P2);
+#endif
+  if (ws_bytes < (size_t)P * kW * kW * sizeof(float) || ws_bytes < (size_t)P2 * kEncPad * 2 * kW * sizeof(float)) {
     set_error("wgrad workspace too small: %zu < %zu", ws_bytes, (size_t)P * kW * kW * sizeof(float));
     return PXO_ERR_WORKSPACE;
   }
   float* slab = reinterpret_cast<float*>(ws);
   const int64_t MW = M * kW;
-  auto reduce = [&](int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld) {
+  auto reduce2 = [&](int np, int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld, float* dst2,
+                     int col0_2) {
     const int n4 = kin * nout / 4;
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((n4 + 63) / 64), dim3(256), 0, s, slab, P, kin, nout,
-                       rows_valid, col0, ncols, dst, dst_ld);
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((n4 + 63) / 64), dim3(256), 0, s, slab, np, kin, nout,
+                       rows_valid, col0, ncols, dst, dst_ld, dst2, col0_2);
   };
+  auto reduce = [&](int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld) {
+    reduce2(P, kin, nout, rows_valid, col0, ncols, dst, dst_ld, nullptr, 0);
+  };
+#if PXO_WGRAD_SMALL == 0
   // Dense_0: enc^T dz_0  (63 valid input rows)
   hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc, dz,
                      nullptr, 0, M, rpw, P, slab);
   reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW);
+#else
+  // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
+  {
+    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
+    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true>), dim3(P2), dim3(256), 0, s, enc, dz,
+                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
+  }
+  reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW,
+          grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
+#endif
   // Dense_1..7: h_{l-1}^T dz_l  (for l = 5 these are the first 256 input rows)
   for (int l = 1; l < kDepth; ++l) {
     {
@@ -306,18 +349,23 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
     }
     reduce(kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW);
   }
+#if PXO_WGRAD_SMALL == 0
   // Dense_5 skip rows 256..318: enc^T dz_5
   hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc,
                      dz + (int64_t)5 * MW, nullptr, 0, M, rpw, P, slab);
   reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
+#endif
   // heads: h7^T [d_raw_rgb | d_raw_sigma]
   const float* h7 = acts + (int64_t)7 * MW;
   const int nhb = head_blocks(deg);
-  if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw, P, slab, s);
-  else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw, P, slab, s);
-  else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw, P, slab, s);
-  reduce(kW, 32 * nhb, kW, 0, C, grads + leaf_kernel_off(9, deg), C);
-  reduce(kW, 32 * nhb, kW, C, 1, grads + leaf_kernel_off(8, deg), 1);
+  {
+    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
+    if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+    else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+    else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+  }
+  reduce2(P2, kW, 32 * nhb, kW, 0, C, grads + leaf_kernel_off(9, deg), C, nullptr, 0);
+  reduce2(P2, kW, 32 * nhb, kW, C, 1, grads + leaf_kernel_off(8, deg), 1, nullptr, 0);
   // biases
   hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, (int64_t)mlp_bwd_partials(M), deg, grads);
   return check_launch("mlp_bwd_weights");

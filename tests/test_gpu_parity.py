@@ -190,6 +190,51 @@ def test_mlp_backward(deg, M):
     close("param grads", grads, leaf.grad, rtol=1e-3, atol=1e-5 * max(gscale, 1.0))
 
 
+@pytest.mark.parametrize("deg", [3, 4])
+def test_half_height_tail_tiles(deg):
+    """Launches larger than one round of tiles whose remainder fits one round at half height run that remainder as
+    64-row tiles (pxo_common.h TileSched; e.g. the fine pass of BASELINE configs[1]: 24 rounds + 157 half tiles).
+    Rows are independent of the tile they sit in, so every output row must be BIT-identical to the same row evaluated
+    inside a small launch (full tiles only); the weight gradients, sums over rows, agree to summation order."""
+    ops = _ops(); dev = _gpu()
+    from plenoctree_amd import _lib
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_head = cus * _lib.load().pxo_tile_rows()            # one whole round of full tiles
+    N = n_head + 5000                                      # + 79 half tiles (40 full tiles' worth of rows)
+    cfg = O.Cfg(sh_deg=deg); pcfg = pxo_cfg(ops, cfg)
+    flat = make_params(cfg)
+    mlp_flat = split_mlp(flat, cfg, 1).to(dev)
+    pf, pb = ops.pack_weights(pcfg, mlp_flat)
+    gen = torch.Generator().manual_seed(17)
+    pts = ((torch.rand(N, 3, generator=gen) * 2 - 1) * 2.0).to(dev)
+    C = cfg.num_rgb_channels
+    d_rgb = (torch.randn(N, C, generator=gen) * 0.1).to(dev)
+    d_sigma = (torch.randn(N, generator=gen) * 0.1).to(dev)
+    parts = [slice(0, n_head), slice(n_head, n_head + 2048), slice(n_head + 2048, N)]     # each: full tiles only
+    # inference path, with and without raw_rgb (sigma-only head)
+    rgb, sig = ops.eval_points(pcfg, pf, pts)
+    _, sig_only = ops.eval_points(pcfg, pf, pts, want_rgb=False)
+    assert torch.equal(sig, sig_only)
+    for sl in parts:
+        r, s_ = ops.eval_points(pcfg, pf, pts[sl].contiguous())
+        assert torch.equal(r, rgb[sl]) and torch.equal(s_, sig[sl])
+    # training path: saved activations, relu mask -> backward(data) -> weight gradients
+    raw_rgb, raw_sigma, (acts, enc, mask) = ops.mlp_fwd(pcfg, pf, pts, save=True)
+    assert torch.equal(raw_rgb, rgb) and torch.equal(raw_sigma, sig[:, 0])
+    dz, dbias = ops.mlp_bwd_data(pcfg, pb, d_rgb, d_sigma, mask)
+    grads = ops.mlp_bwd_weights(pcfg, acts, enc, dz, d_rgb, d_sigma, dbias)
+    g_sum = torch.zeros_like(grads, dtype=torch.float64)
+    for sl in parts:
+        p = pts[sl].contiguous(); dr = d_rgb[sl].contiguous(); ds = d_sigma[sl].contiguous()
+        _, _, (a2, e2, m2) = ops.mlp_fwd(pcfg, pf, p, save=True)
+        assert torch.equal(a2, acts[:, sl]) and torch.equal(e2, enc[sl])
+        dz2, db2 = ops.mlp_bwd_data(pcfg, pb, dr, ds, m2)
+        assert torch.equal(dz2, dz[:, sl])
+        g_sum += ops.mlp_bwd_weights(pcfg, a2, e2, dz2, dr, ds, db2).double()
+    gs = float(g_sum.abs().max())
+    close("weight gradients: one launch vs sum of three", grads, g_sum, rtol=1e-4, atol=1e-6 * gs)
+
+
 def test_sample_along_rays():
     ops = _ops(); dev = _gpu()
     rays = make_rays(300)

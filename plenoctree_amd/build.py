@@ -89,6 +89,8 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--variants" in sys.argv:   # A/B libraries for one GPU session (selected at run time with PXO_LIB)
         build(suffix="_bd2", extra_flags=("-DPXO_BDIST=2",))     # weight fragments fetched 2 k-groups ahead (3 = default)
+        build(suffix="_ws0", extra_flags=("-DPXO_WGRAD_SMALL=0",))       # round-1 skinny weight-gradient kernels
+        build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
     if "--wgrad-variants" in sys.argv:
         for v in (1, 2, 3, 4):
             build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))

@@ -5,7 +5,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 R=$PWD
-for sfx in ${LIBS:-"main _bd2 _ws0 _nohalf"}; do
+LIBS=${LIBS:-main _bd2 _ws0 _nohalf}
+for sfx in $LIBS; do
   [ "$sfx" = "main" ] && lib=$R/plenoctree_amd/libplenoctree_hip.so || lib=$R/plenoctree_amd/libplenoctree_hip$sfx.so
   [ -f "$lib" ] || { echo "missing $lib"; continue; }
   PXO_LIB=$lib timeout 300 python bench.py --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --no-extras ${AB_ARGS:-} > gpurun_out/ab$sfx.json 2> gpurun_out/ab$sfx.err

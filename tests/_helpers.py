@@ -125,7 +125,7 @@ def oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_points, dtyp
         _, sig = O.eval_points_raw(params, cast(sp_points), cfg)
         lsp = cfg.sparsity_weight * (1.0 - torch.exp(-cfg.sparsity_length * torch.relu(sig)).mean())
         tail = tail + lsp
-        loss_sp = float(lsp)
+        loss_sp = float(lsp.detach())
     leaves = [t for mlp in params for pair in mlp for t in pair]
     weight_l2 = sum((z ** 2).sum() for z in leaves) / sum(z.numel() for z in leaves)
     tail = tail + cfg.weight_decay_mult * weight_l2

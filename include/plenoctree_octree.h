@@ -81,6 +81,15 @@ int pxo_tree_build(const void* ws, size_t ws_bytes, int depth, const int64_t* le
  * u: [n_nodes*8*S, 3] uniforms in [0,1) (pxo_uniform).  points: [n_nodes*8*S, 3], cells in packed order. */
 int pxo_tree_sample_cells(const int32_t* parent_depth, int64_t node0, int64_t n_nodes, int S, const float* u,
                           const float offset[3], const float invradius[3], float* points, void* stream);
+/* The same for arbitrary leaves given by packed cell index node*8 + cell (`tree[leaf_inds].sample(S)` with any index
+ * set, octree/extraction.py:358-369): u [n_cells*S, 3], points [n_cells*S, 3]. */
+int pxo_tree_sample_leaves(const int32_t* parent_depth, const int64_t* packed, int64_t n_cells, int S, const float* u,
+                           const float offset[3], const float invradius[3], float* points, void* stream);
+/* tree[points] (the indexing behind `tree[grid].refine()`, octree/extraction.py:341-350): packed index
+ * node*8 + cell of the leaf that contains each world-space point [n,3] (tree coordinates clamped to
+ * [0, 1 - 1e-6] as svox does). */
+int pxo_tree_query(const int32_t* child, const float* points, int64_t n, const float offset[3],
+                   const float invradius[3], int64_t* packed, void* stream);
 /* tree[:, -1:].relu_()  (octree/extraction.py:503): clamps the sigma channel of n_cells cells at 0. */
 int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream);
 

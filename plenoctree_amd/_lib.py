@@ -112,6 +112,8 @@ SIGNATURES = {
     "pxo_tree_count_nodes": (c_int, [P, c_int, P, c_size_t, POINTER(c_int64), P]),
     "pxo_tree_build": (c_int, [P, c_size_t, c_int, POINTER(c_int64), P, P, P]),
     "pxo_tree_sample_cells": (c_int, [P, c_int64, c_int64, c_int, P, F3, F3, P, P]),
+    "pxo_tree_sample_leaves": (c_int, [P, P, c_int64, c_int, P, F3, F3, P, P]),
+    "pxo_tree_query": (c_int, [P, P, c_int64, F3, F3, P, P]),
     "pxo_tree_relu_sigma": (c_int, [P, c_int64, c_int, P]),
     "pxo_grid_weight_workspace_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "pxo_grid_weight_render": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),

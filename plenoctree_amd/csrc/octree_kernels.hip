@@ -222,6 +222,59 @@ __global__ void tree_sample_cells_kernel(const int32_t* __restrict__ parent_dept
   pts[q * 3 + 2] = (pz - oz) / iz;
 }
 
+// tree[leaf_inds].sample(S) for arbitrary leaves given by their packed cell index (node*8 + cell)
+__global__ void tree_sample_leaves_kernel(const int32_t* __restrict__ parent_depth, const int64_t* __restrict__ packed,
+                                          int64_t n_cells, int S, const float* __restrict__ u, float ox, float oy, float oz,
+                                          float ix, float iy, float iz, float* __restrict__ pts) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;      // (cell, sample)
+  if (q >= n_cells * S) return;
+  const int64_t pk = packed[q / S];
+  int64_t node = pk >> 3;
+  const int cell = (int)(pk & 7);
+  const int depth = parent_depth[node * 2 + 1];
+  uint32_t X = (cell >> 2) & 1, Y = (cell >> 1) & 1, Z = cell & 1;
+  for (int lvl = 1; lvl <= depth; ++lvl) {
+    const int32_t up = parent_depth[node * 2];
+    const int c = up & 7;
+    X |= (uint32_t)((c >> 2) & 1) << lvl;
+    Y |= (uint32_t)((c >> 1) & 1) << lvl;
+    Z |= (uint32_t)(c & 1) << lvl;
+    node = up >> 3;
+  }
+  const float side = 1.0f / (float)((uint32_t)2 << depth);
+  const float px = (float)X * side + u[q * 3] * side;
+  const float py = (float)Y * side + u[q * 3 + 1] * side;
+  const float pz = (float)Z * side + u[q * 3 + 2] * side;
+  pts[q * 3] = (px - ox) / ix;
+  pts[q * 3 + 1] = (py - oy) / iy;
+  pts[q * 3 + 2] = (pz - oz) / iz;
+}
+
+// tree[points]: packed index (node*8 + cell) of the leaf containing each world-space point.  svox's query: tree
+// coordinates clamped to [0, 1 - 1e-6], then per level x *= 2, cell = floor(x), x -= cell until a leaf is reached.
+__global__ void tree_query_kernel(const int32_t* __restrict__ child, const float* __restrict__ pts, int64_t n, float ox,
+                                  float oy, float oz, float ix, float iy, float iz, int64_t* __restrict__ packed) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  float x = fminf(fmaxf(ox + ix * pts[q * 3], 0.0f), 1.0f - 1e-6f);
+  float y = fminf(fmaxf(oy + iy * pts[q * 3 + 1], 0.0f), 1.0f - 1e-6f);
+  float z = fminf(fmaxf(oz + iz * pts[q * 3 + 2], 0.0f), 1.0f - 1e-6f);
+  int64_t node = 0;
+  for (int lvl = 0; lvl <= kMaxD + 1; ++lvl) {
+    x *= 2.0f; y *= 2.0f; z *= 2.0f;
+    const int i = (int)floorf(x), j = (int)floorf(y), k = (int)floorf(z);
+    x -= (float)i; y -= (float)j; z -= (float)k;
+    const int cell = (i * 2 + j) * 2 + k;
+    const int32_t skip = child[node * 8 + cell];
+    if (skip == 0) {
+      packed[q] = node * 8 + cell;
+      return;
+    }
+    node += skip;
+  }
+  packed[q] = -1;    // deeper than any valid tree: corrupt child array
+}
+
 __global__ void tree_relu_sigma_kernel(float* __restrict__ data, int64_t n_cells, int dim) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n_cells) {
@@ -766,6 +819,28 @@ int pxo_tree_sample_cells(const int32_t* parent_depth, int64_t node0, int64_t n_
                      parent_depth, node0, n_nodes, S, u, offset[0], offset[1], offset[2], invradius[0], invradius[1],
                      invradius[2], points);
   return check_launch("tree_sample_cells");
+}
+
+int pxo_tree_sample_leaves(const int32_t* parent_depth, const int64_t* packed, int64_t n_cells, int S, const float* u,
+                           const float offset[3], const float invradius[3], float* points, void* stream) {
+  PXO_REQUIRE(n_cells >= 0 && S >= 1, "pxo_tree_sample_leaves: bad sizes");
+  if (n_cells == 0) return PXO_OK;
+  PXO_REQUIRE(parent_depth && packed && u && offset && invradius && points, "pxo_tree_sample_leaves: null pointer");
+  const int64_t n = n_cells * S;
+  hipLaunchKernelGGL(tree_sample_leaves_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     parent_depth, packed, n_cells, S, u, offset[0], offset[1], offset[2], invradius[0], invradius[1],
+                     invradius[2], points);
+  return check_launch("tree_sample_leaves");
+}
+
+int pxo_tree_query(const int32_t* child, const float* points, int64_t n, const float offset[3], const float invradius[3],
+                   int64_t* packed, void* stream) {
+  PXO_REQUIRE(n >= 0, "pxo_tree_query: n < 0");
+  if (n == 0) return PXO_OK;
+  PXO_REQUIRE(child && points && offset && invradius && packed, "pxo_tree_query: null pointer");
+  hipLaunchKernelGGL(tree_query_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, child, points,
+                     n, offset[0], offset[1], offset[2], invradius[0], invradius[1], invradius[2], packed);
+  return check_launch("tree_query");
 }
 
 int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream) {

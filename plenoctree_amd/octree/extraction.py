@@ -142,6 +142,7 @@ def tree_center_radius(tree):
     return center.tolist(), radius.tolist()
 
 
+@torch.no_grad()
 def eval_octree(tree, dataset, args, comm=None, want_frames=False, want_ssim=False):
     """eval_octree (octree/nerf/utils.py:448-497): mean PSNR (and SSIM if asked) of the octree renders of a split;
     images are sharded over the ranks.  LPIPS needs pretrained VGG weights, which cannot be fetched here."""

@@ -61,14 +61,15 @@ class TreeOptimizer:
     def step(self, grad_scale=1.0):
         a = self.args
         if a.sgd:
-            oops.sgd_step(self.tree.data, self.grad, a.lr * grad_scale, a.sgd_momentum, a.sgd_nesterov, self.buf,
+            oops.sgd_step(self.tree.data.data, self.grad, a.lr * grad_scale, a.sgd_momentum, a.sgd_nesterov, self.buf,
                           first_step=self.step_count == 0)
         else:
-            ops.adam_step(self.tree.data.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), a.lr,
+            ops.adam_step(self.tree.data.data.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), a.lr,
                           self.step_count, grad_scale=grad_scale)
         self.step_count += 1
 
 
+@torch.no_grad()
 def train_image(renderer, opt, c2w, gt, H, W, focal):
     """One image: accumulates d mse / d data into opt.grad and returns the device scalar sum of squares."""
     im = renderer.render_persp(c2w, width=W, height=H, fx=focal, fast=False)
@@ -77,6 +78,7 @@ def train_image(renderer, opt, c2w, gt, H, W, focal):
     return sse
 
 
+@torch.no_grad()
 def run_validation(renderer, c2ws, images, H, W, focal, comm):
     acc = torch.zeros(2, dtype=torch.float64, device=renderer.tree.device)
     for j in range(comm.rank, len(c2ws), comm.world):
@@ -88,6 +90,7 @@ def run_validation(renderer, c2ws, images, H, W, focal, comm):
     return float(acc[0] / acc[1])
 
 
+@torch.no_grad()
 def fit(args, tree, train, val, H, W, focal, comm, say=print):
     """The epoch loop of octree/optimization.py:189-243.  train/val = (c2w [n,4,4], list of [H,W,3] images).
     Rank r takes image j0 + r of every group of `world` images; the group's gradients are summed with one

@@ -72,6 +72,34 @@ def tree_sample_cells(parent_depth, node0, n_nodes, samples, offset, invradius, 
     return pts
 
 
+def tree_sample_leaves(parent_depth, packed, samples, offset, invradius, u=None, seed=0, stream_id=0):
+    """World-space sample points [n, samples, 3] inside the leaves `packed` (int64 node*8+cell)."""
+    _require_gpu()
+    lib = _lib.load()
+    if packed.dtype != torch.int64:
+        raise PxoError("packed leaf indices must be int64")
+    n_cells = packed.numel()
+    n = n_cells * samples
+    dev = parent_depth.device
+    if u is None:
+        u = _new(max(n * 3, 1), device=dev)
+        check(lib.pxo_uniform(seed, stream_id, n * 3, 0.0, 1.0, _f(u), _stream()), "pxo_uniform")
+    pts = _new(n_cells, samples, 3, device=dev)
+    check(lib.pxo_tree_sample_leaves(_p(parent_depth), _p(packed.contiguous()), n_cells, samples, _f(u), _vec3(offset),
+                                     _vec3(invradius), _f(pts), _stream()), "pxo_tree_sample_leaves")
+    return pts
+
+
+def tree_query(child, points, offset, invradius):
+    """Packed index (node*8 + cell, int64 [n]) of the leaf containing each world-space point [n,3]."""
+    _require_gpu()
+    points = points.reshape(-1, 3).contiguous().float()
+    out = _new(points.shape[0], device=points.device, dtype=torch.int64)
+    check(_lib.load().pxo_tree_query(_p(child), _f(points), points.shape[0], _vec3(offset), _vec3(invradius), _p(out),
+                                     _stream()), "pxo_tree_query")
+    return out
+
+
 def tree_relu_sigma(data):
     _require_gpu()
     dim = data.shape[-1]

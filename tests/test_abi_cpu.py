@@ -86,11 +86,13 @@ def test_size_queries(lib):
     # 8 trunk layers (64 + 4*256 + 320 + 2*256 rows) x 256 + head 256x64 + biases 8*256+64
     assert a.value == (64 + 4 * 256 + 320 + 2 * 256) * 256 + 256 * 64 + 8 * 256 + 64
     assert b.value == 64 * 256 + 7 * 256 * 256
-    # 1 bit per activation, whole tiles
+    # 1 bit per activation, whole 128-row tile slots, + 512 spare slots for the half-height tail tiles of a ragged
+    # last round (pxo_common.h TileSched)
     tm = lib.pxo_tile_rows()
-    assert tm in (64, 128)
-    assert lib.pxo_relu_mask_bytes(128) == 8 * 128 * 256 // 8
-    assert lib.pxo_relu_mask_bytes(129) == 8 * (128 + tm) * 256 // 8
+    assert tm == 128
+    slot = 8 * 128 * 256 // 8
+    assert lib.pxo_relu_mask_bytes(128) == (1 + 512) * slot
+    assert lib.pxo_relu_mask_bytes(129) == (2 + 512) * slot
     assert lib.pxo_dbias_partial_bytes(128) == 1024 * 9 * 256 * 4   # one [9][256] slot per persistent workgroup
     nbytes = ctypes.c_size_t(0)
     assert lib.pxo_train_workspace_bytes(ctypes.byref(cfg), 4096, ctypes.byref(nbytes)) == 0

@@ -81,16 +81,18 @@ def _patch(structure):
         return _render64(structure, view.data.double(), c2w.numpy(), _opt(opts)).float()
 
     def octree_render_persp_bwd(view, c2w, width, height, fx, opts, grad_out, grad_data, fy=None, out_rgb=None):
-        d = view.data.double().detach().requires_grad_(True)
-        (_render64(structure, d, c2w.numpy(), _opt(opts)) * grad_out.double()).sum().backward()
+        with torch.enable_grad():              # the drivers run under torch.no_grad(); the stand-in differentiates the oracle
+            d = view.data.double().detach().requires_grad_(True)
+            (_render64(structure, d, c2w.numpy(), _opt(opts)) * grad_out.double()).sum().backward()
         grad_data += d.grad.float()
         return grad_data
 
     def image_mse(im, gt, want_grad=True):
-        x = im.detach().clone().requires_grad_(True)
-        sse = ((x.clamp(0.0, 1.0) - gt) ** 2).sum()
-        if want_grad:
-            (sse / x.numel()).backward()
+        with torch.enable_grad():
+            x = im.detach().clone().requires_grad_(True)
+            sse = ((x.clamp(0.0, 1.0) - gt) ** 2).sum()
+            if want_grad:
+                (sse / x.numel()).backward()
         return sse.detach().reshape(1), (x.grad if want_grad else None)
 
     def sgd_step(params, grads, lr, momentum=0.0, nesterov=False, buf=None, first_step=False):
@@ -160,7 +162,7 @@ def _worker(rank, world, port, outdir):
     psnr, _ = extraction.eval_octree(tree, ds, args, comm)
     # step 2 on a fresh copy of the structure: nodes sharded, blocks all-gathered
     tree2 = _host_tree(t)
-    tree2.data.zero_()
+    tree2.data.data.zero_()
     extraction.step2(args, tree2, _Model, None, comm, seed=0)
     # weight mask: cameras sharded, max-reduced
     sig = torch.linspace(-2.0, 2.0, 8 ** 3)

@@ -12,7 +12,7 @@ import torch
 
 from oracle import nerf_oracle as O
 from oracle import octree_oracle as T
-from test_gpu_parity import _gpu, close, make_params
+from _helpers import _gpu, close, make_params
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -271,6 +271,84 @@ def test_octree_render_every_lanes_per_ray_template(lanes):
     from plenoctree_amd import _lib
     with pytest.raises(_lib.PxoError, match="lanes"):
         oops.set_lanes_per_ray(5, 0)
+
+
+def test_svox_call_surface_on_device():
+    """The svox indexing surface the reference's extraction uses (octree/extraction.py:337-394,:503), call for call,
+    on the device: `tree[grid].refine()` x depth, `tree.depths`, `tree[inds].sample(S)`, `tree[inds] = rgba`,
+    `tree[:, -1:].relu_()`.  (tests/test_reference_drivers_cpu.py runs the reference's own step1/step2 on the same
+    classes with oracle-backed kernels; /root/reference does not exist on this box.)"""
+    oops = _oops(); dev = _gpu()
+    from plenoctree_amd.octree import svox
+    depth, K, center, radius = 3, 4, [0.1, 0.0, -0.2], [1.4, 1.5, 1.3]
+    reso = 2 ** (depth + 1)
+    mask = _mask(depth, 77, 0.1)
+    want = T.build_from_mask(mask, depth, 3 * K + 1, center, radius)
+
+    def new_tree():
+        return svox.N3Tree(N=2, data_dim=3 * K + 1, init_refine=0, init_reserve=500000, geom_resize_fact=1.0,
+                           depth_limit=depth, radius=radius, center=center, data_format=f"SH{K}", extra_data=None,
+                           map_location=dev)
+
+    tree = new_tree()
+    assert tree.offset.device.type == "cpu" and torch.equal(tree.offset.cpu(), torch.from_numpy(want.offset))
+    # leaf lookup against the oracle's descent, including points outside the volume (clamped) and on cell faces
+    rs = np.random.RandomState(5)
+    probe = np.concatenate([rs.uniform(-2.0, 2.0, (500, 3)), T.grid_points(reso, want.offset, want.invradius)[::7]]).astype(f32)
+    fine = svox.N3Tree(N=2, data_dim=3 * K + 1, depth_limit=depth, radius=radius, center=center, data_format=f"SH{K}",
+                       map_location=dev).refine_from_mask(torch.from_numpy(mask.astype(np.uint8)).to(dev))
+    got = oops.tree_query(fine.child, torch.from_numpy(probe).to(dev), fine.offset, fine.invradius).cpu().numpy()
+    ref = []
+    for pnt in probe:
+        n, i, j, k, _, _ = want.query(want.world2tree(pnt))
+        ref.append(((n * 2 + i) * 2 + j) * 2 + k)
+    assert np.array_equal(got, np.asarray(ref))
+    # octree/extraction.py:337-350
+    arr = (torch.arange(0, reso, dtype=torch.float32) + 0.5) / reso
+    xx, yy, zz = [(arr - tree.offset.cpu()[a]) / tree.invradius.cpu()[a] for a in range(3)]
+    grid = torch.stack(torch.meshgrid(xx, yy, zz, indexing="ij")).reshape(3, -1).T
+    grid = grid[torch.from_numpy(mask.reshape(-1))].to(dev)
+    for _ in range(depth - 1):
+        tree[grid].refine()
+    half = grid.shape[0] // 2                        # "do last layer separately" in chunks (:345-350)
+    tree[grid[:half]].refine()
+    tree[grid[half:]].refine()
+    assert tree.max_depth == depth and tree.n_internal == want.n_internal
+    # chunked refinement appends the last level chunk by chunk: same tree, node order of that level differs; one-shot
+    # refinement reproduces the oracle's (and refine_from_mask's) arrays exactly
+    one = new_tree()
+    for _ in range(depth):
+        one[grid].refine()
+    assert np.array_equal(one.child.cpu().numpy(), want.child) and np.array_equal(one.parent_depth.cpu().numpy(), want.parent_depth)
+    assert torch.equal(one.child, fine.child) and torch.equal(one.parent_depth, fine.parent_depth)
+    assert np.array_equal(one.depths.cpu().numpy(), want.depths())
+    for t in (tree, one):
+        # :358-394
+        leaf_mask = t.depths.cpu() == t.max_depth
+        leaf_ind = torch.where(leaf_mask)[0]
+        assert leaf_ind.numel() == 8 * int((want.parent_depth[:, 1] == depth).sum())
+        S = 5
+        for i in range(0, leaf_ind.size(0), 300):
+            chunk_inds = leaf_ind[i:i + 300]
+            points = t[chunk_inds].sample(S)
+            assert points.shape == (chunk_inds.numel(), S, 3)
+            packed = t._leaf_packed()[chunk_inds.to(dev)]
+            again = oops.tree_query(t.child, points.view(-1, 3), t.offset, t.invradius).view(-1, S)
+            assert torch.equal(again, packed[:, None].expand(-1, S))          # every sample lies inside its own leaf
+            assert float(points.view(-1, S, 3).std(dim=1).min()) > 0          # and they are distinct
+            rgba = torch.cat([points.mean(dim=1), points.new_full((points.shape[0], 3 * K - 3), 0.25),
+                              points[:, 0, :1] - 0.1], -1)
+            t[chunk_inds] = rgba
+            assert torch.equal(t.data.data.view(-1, 3 * K + 1)[packed], rgba)
+        flat = t.data.data.view(-1, 3 * K + 1)
+        deep = t._leaf_packed()[leaf_ind.to(dev)]
+        untouched = torch.ones(flat.shape[0], dtype=torch.bool, device=dev); untouched[deep] = False
+        assert float(flat[untouched].abs().max()) == 0.0
+        assert bool((flat[:, -1] < 0).any())
+        t[:, -1:].relu_()
+        assert float(t.data.data[..., -1].min()) == 0.0 and bool((t.data.data[..., 0] < 0).any())
+    # both trees render the same image (same geometry, same leaf values up to the random samples -> compare structure only)
+    assert tree.parameters()[0] is tree.data and tree.data.requires_grad
 
 
 def test_sgd_step_matches_torch():

@@ -152,3 +152,22 @@ def test_nsvf_loader_on_a_synthetic_directory(tmp_path):
     a.factor = 2
     half = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=4)
     assert (half.h, half.w) == (3, 4) and half.focal == pytest.approx(15.5)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run, one rank per GPU
+    (rendezvous on 127.0.0.1); with too few devices it says so instead of asking for a wrapper."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "7"], 23456)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "23456"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7"]
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and "only 0 ROCm device(s) visible" in (r.stderr + r.stdout)

@@ -91,6 +91,9 @@ if __name__ == "__main__":
         build(suffix="_bd2", extra_flags=("-DPXO_BDIST=2",))     # weight fragments fetched 2 k-groups ahead (3 = default)
         build(suffix="_ws0", extra_flags=("-DPXO_WGRAD_SMALL=0",))       # round-1 skinny weight-gradient kernels
         build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
+    if "--variants2" in sys.argv:
+        build(suffix="_wsched0", extra_flags=("-DPXO_WGRAD_SCHED=0",))   # wgrad: next chunk's loads/stores at the chunk boundary
+        build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
     if "--wgrad-variants" in sys.argv:
         for v in (1, 2, 3, 4):
             build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))

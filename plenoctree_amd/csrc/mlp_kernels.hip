@@ -293,6 +293,31 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
   }
 }
 
+// relu mask, one bit per accumulator element in (row block, column block, register) order, packed MSB-first:
+// the forward epilogue shifts the bit "v > 0" in from the carry (mw = 2 mw + bit: compare + add-with-carry), the
+// backward epilogue shifts it out again into the carry that selects the gradient (add + select).
+#ifndef PXO_MASK_ASM
+#define PXO_MASK_ASM 1
+#endif
+__device__ __forceinline__ void mask_push(uint32_t& mw, float v) {
+#if PXO_MASK_ASM
+  asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mw) : "v"(v) : "vcc");
+#else
+  mw = (mw << 1) | (v > 0.f ? 1u : 0u);
+#endif
+}
+__device__ __forceinline__ float mask_pop(uint32_t& mw, float x) {
+#if PXO_MASK_ASM
+  float r;
+  asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc" : "+v"(mw), "=v"(r) : "v"(x) : "vcc");
+  return r;
+#else
+  const float r = (mw & 0x80000000u) ? x : 0.f;
+  mw <<= 1;
+  return r;
+#endif
+}
+
 constexpr int kRB = kTM / 32;                    // row blocks of a full tile (all owned by every wave)
 constexpr int kCB = 8 / kMlpWaves;               // column blocks per wave in a 256-wide layer (1)
 
@@ -366,10 +391,7 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
           const int row = r * 32 + frag_row(reg, lane_e);
           const float v = fmaxf(acc[r][c][reg] + b, 0.f);
           lds[row * kLDA + col] = v;
-          if (SAVE) {
-            const int bit = (r * kCB + c) * 16 + reg;
-            if (v > 0.f) mw[bit >> 5] |= 1u << (bit & 31);
-          }
+          if (SAVE) mask_push(mw[((r * kCB + c) * 16 + reg) >> 5], v);
         }
       }
     if (SAVE) {
@@ -546,8 +568,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = r * 32 + frag_row(reg, lane_e);
-          const int bit = (r * kCB + c) * 16 + reg;
-          const float v = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? acc[r][c][reg] : 0.f;
+          const float v = mask_pop(mw[((r * kCB + c) * 16 + reg) >> 5], acc[r][c][reg]);
           lds[row * kLDA + col] = v;
           colsum += v;
         }

@@ -12,6 +12,9 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
+#ifndef PXO_WGRAD_SCHED
+#define PXO_WGRAD_SCHED 1         // 1: next chunk's loads / LDS stores issued under this chunk's MFMAs (0: at the chunk boundary)
+#endif
 #ifndef PXO_WGRAD_SMALL
 #define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
 #endif
@@ -134,7 +137,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    const bool more = ch + 1 < nchunks;
+#if PXO_WGRAD_SCHED == 0
+    if (more) load_chunk(ch + 1);
+#endif
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
@@ -160,12 +166,25 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
+#if PXO_WGRAD_SCHED != 0
+      // the next chunk's global loads (address arithmetic + 6 loads) are issued under the first MFMA group of this
+      // chunk, and its LDS stores under the last one: the stretch between a chunk's last MFMA and the next chunk's
+      // first is then only "barrier + first operand reads"
+      if (kk == 0 && more) load_chunk(ch + 1);
+      if (kk == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
       read_step(kk + 4 < KCH ? kk + 4 : kk + 2, a0, b0);   // harmless re-read on the last trip
       __builtin_amdgcn_sched_barrier(0);
+#if PXO_WGRAD_SCHED != 0
+      if (kk + 4 >= KCH && more) store_chunk(buf ^ 1);
+      if (kk + 4 >= KCH) __builtin_amdgcn_sched_barrier(0);
+#endif
       mfma_step(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+#if PXO_WGRAD_SCHED == 0
+    if (more) store_chunk(buf ^ 1);
+#endif
     __syncthreads();
   }
 

@@ -92,8 +92,9 @@ if __name__ == "__main__":
         build(suffix="_ws0", extra_flags=("-DPXO_WGRAD_SMALL=0",))       # round-1 skinny weight-gradient kernels
         build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
     if "--variants2" in sys.argv:
-        build(suffix="_wsched0", extra_flags=("-DPXO_WGRAD_SCHED=0",))   # wgrad: next chunk's loads/stores at the chunk boundary
         build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
+    if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)
+        build(suffix="_abl_nostore", extra_flags=("-DPXO_ABLATE_STORE",))   # fused MLP kernels without the tile copy to HBM
     if "--wgrad-variants" in sys.argv:
         for v in (1, 2, 3, 4):
             build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))

@@ -283,6 +283,9 @@ __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 
 template <int RBN>
 __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
                                            int64_t M, bool full, int tid) {
+#ifdef PXO_ABLATE_STORE        // timing experiment only (results are wrong): what the LDS -> HBM tile copy costs
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 32 * RBN * kW / 4 / kMlpThreads; ++i) {
     const int idx = tid + kMlpThreads * i;

@@ -12,9 +12,6 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
-#ifndef PXO_WGRAD_SCHED
-#define PXO_WGRAD_SCHED 1         // 1: next chunk's loads / LDS stores issued under this chunk's MFMAs (0: at the chunk boundary)
-#endif
 #ifndef PXO_WGRAD_SMALL
 #define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
 #endif
@@ -24,7 +21,7 @@ constexpr int kKC = 32;           // row granularity of the split (rows_per_wg i
 // row range are placed 8 blocks apart = on the same XCD so the second read of X hits L2).
 // DUAL: the NOUT = 512 columns are two row-major [M,256] arrays side by side (dZ | dZ2): Dense_0 and the skip rows of
 // Dense_5 share X = enc (model_utils.py:70-71), so one pass over enc produces both gradients.
-template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false>
+template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false, int SCHED = 0>
 __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
     int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr) {
@@ -138,9 +135,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
     const bool more = ch + 1 < nchunks;
-#if PXO_WGRAD_SCHED == 0
-    if (more) load_chunk(ch + 1);
-#endif
+    if (SCHED == 0 && more) load_chunk(ch + 1);
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
@@ -166,25 +161,20 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-#if PXO_WGRAD_SCHED != 0
+      // SCHED 1 (the skinny, HBM-heavy products; the 256x256 product measured 2 % slower with it):
       // the next chunk's global loads (address arithmetic + 6 loads) are issued under the first MFMA group of this
       // chunk, and its LDS stores under the last one: the stretch between a chunk's last MFMA and the next chunk's
       // first is then only "barrier + first operand reads"
-      if (kk == 0 && more) load_chunk(ch + 1);
-      if (kk == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
+      if (SCHED != 0 && kk == 0 && more) load_chunk(ch + 1);
+      if (SCHED != 0 && kk == 0) __builtin_amdgcn_sched_barrier(0);
       read_step(kk + 4 < KCH ? kk + 4 : kk + 2, a0, b0);   // harmless re-read on the last trip
       __builtin_amdgcn_sched_barrier(0);
-#if PXO_WGRAD_SCHED != 0
-      if (kk + 4 >= KCH && more) store_chunk(buf ^ 1);
-      if (kk + 4 >= KCH) __builtin_amdgcn_sched_barrier(0);
-#endif
+      if (SCHED != 0 && kk + 4 >= KCH && more) store_chunk(buf ^ 1);
+      if (SCHED != 0 && kk + 4 >= KCH) __builtin_amdgcn_sched_barrier(0);
       mfma_step(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if PXO_WGRAD_SCHED == 0
-    if (more) store_chunk(buf ^ 1);
-#endif
+    if (SCHED == 0 && more) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
@@ -291,7 +281,7 @@ static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const floa
 #else
   // 4 waves, each 64 rows x all head columns (4 LDS operand reads per 4 MFMAs instead of 3 per 2), 40 KB of LDS:
   // several workgroups per CU
-  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
+  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
                      d_raw_sigma, C, M, rpw, P, slab);
 #endif
 }
@@ -335,7 +325,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
   {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
-    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true>), dim3(P2), dim3(256), 0, s, enc, dz,
+    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
                        nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
   }
   reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW,

@@ -76,6 +76,29 @@ def main(src, dst_dir, tag):
     with open(os.path.join(dst_dir, f"{tag}_pmc.md"), "w") as g:
         g.write("\n".join(out) + "\n")
     print("\n".join(out))
+    # HBM bytes per launch for bench.py's roofline.traffic (FETCH_SIZE x2: the gfx950 under-count of wide coalesced
+    # reads, MI355X_MICROARCH.md "HBM"; both counters are KiB)
+    traffic = {"source": f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python "
+                         "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`; FETCH_SIZE x2 (gfx950 under-count of "
+                         "wide coalesced reads, MI355X_MICROARCH.md), KiB units, averaged over the coarse and fine launches",
+               "kernels": {}}
+    for k, r in rows.items():
+        if "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+            name = k.replace("pxo::", "").split("<")[0]
+            ent = traffic["kernels"].setdefault(name, {"hbm_read_bytes_per_launch": 0, "hbm_write_bytes_per_launch": 0,
+                                                       "_launches": 0})
+            n = r["_n"]          # several template instances of one kernel name: launch-weighted average
+            ent["hbm_read_bytes_per_launch"] += r["FETCH_SIZE"] * 2 * 1024 * n
+            ent["hbm_write_bytes_per_launch"] += r["WRITE_SIZE"] * 1024 * n
+            ent["_launches"] += n
+    for ent in traffic["kernels"].values():
+        n = ent.pop("_launches")
+        ent["hbm_read_bytes_per_launch"] = int(ent["hbm_read_bytes_per_launch"] / n)
+        ent["hbm_write_bytes_per_launch"] = int(ent["hbm_write_bytes_per_launch"] / n)
+    if traffic["kernels"]:
+        import json
+        with open(os.path.join(dst_dir, "hbm_traffic.json"), "w") as g:
+            json.dump(traffic, g, indent=1)
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the tt_sh25 / render_fwd / grid512 records")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
-    p.add_argument("--cpu-steps", type=int, default=3)
+    p.add_argument("--cpu-steps", type=int, default=8)
     return p.parse_args(argv)
 
 

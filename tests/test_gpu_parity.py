@@ -615,6 +615,33 @@ def test_generate_rays_and_randint():
         close("multi-camera rays", got, torch.from_numpy(np.ascontiguousarray(want)).reshape(-1, 3)[pick], rtol=1e-6, atol=1e-6)
 
 
+def test_image_batching_feeder_on_device():
+    """--image_batching true (nerf_sh/nerf/datasets.py:137-141,152-157): one batch draws rays from all images; every
+    (ray, pixel) pair of the batch is the pair of its own image, and a train step runs on it."""
+    ops = _ops(); dev = _gpu()
+    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
+    utils.update_flags(args); args.factor = 16; args.image_batching = True
+    ds = datasets.get_dataset("train", args, dev, batch_size=512)
+    b = next(ds)
+    hw = ds.h * ds.w
+    assert b["pixels"].shape == (512, 3) and b["rays"].origins.shape == (512, 3)
+    cams = torch.from_numpy(ds.camtoworlds[:, :3, 3]).to(dev)
+    cam_of_ray = (b["rays"].origins[:, None, :] - cams[None]).abs().sum(-1).argmin(dim=1)
+    assert len(torch.unique(cam_of_ray)) > 20                                  # spans many images
+    for c in torch.unique(cam_of_ray)[:5].tolist():
+        full = ds.get_image(c)
+        sel = cam_of_ray == c
+        d_all = full["rays"].directions.reshape(-1, 3); px_all = full["pixels"].reshape(-1, 3)
+        idx = (b["rays"].directions[sel][:, None, :] - d_all[None]).abs().sum(-1).argmin(dim=1)
+        assert float((d_all[idx] - b["rays"].directions[sel]).abs().max()) < 1e-6
+        assert torch.equal(px_all[idx], b["pixels"][sel])
+    model, params = models.construct_nerf(args, dev)
+    state = models.TrainState(model.cfg, params)
+    stats = models.train_step(model, state, b, 5e-4, seed=1)
+    assert bool(torch.isfinite(stats).all()) and state.step == 1
+
+
 def test_mean_over_samples():
     ops = _ops(); dev = _gpu()
     for deg, S in ((3, 8), (4, 256)):

@@ -233,6 +233,17 @@ def run_train(job, preset, steps, warmup):
     return out
 
 
+def split_precision_twin(tr):
+    """Model/state pair with the same parameters and PxoCfg.mlp_precision = bf16x3 (opt-in inference path)."""
+    from plenoctree_amd.nerf_sh.nerf import models
+    cfg = type(tr["model"].cfg).from_buffer_copy(tr["model"].cfg)
+    cfg.mlp_precision = 1
+    twin = dict(tr)
+    twin["model"] = models.NerfModel(cfg)
+    twin["state"] = models.TrainState(cfg, tr["state"].params.clone())
+    return twin
+
+
 def run_render(job, tr, iters=20):
     """The eval path (nerf_sh/eval.py -> utils.render_image): pxo_render_fwd on `batch` rays per GPU per call,
     deterministic sampling (eval.py:57)."""
@@ -257,7 +268,7 @@ def run_render(job, tr, iters=20):
             "frac": rps / job.world * FLOP_RENDER_PER_RAY[tr["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
 
 
-def run_grid512(job, tr):
+def run_grid512(job, tr, stages_after_grid=True):
     """BASELINE configs[4]: step 1 of octree.extraction at init_grid_depth 8 (octree/extraction.py:288-352):
     sigma of MLP_1 on the 512^3 grid (x-slabs sharded over the ranks + all-gather), the weight mask over the 100
     training views (cameras sharded + max-all-reduce) and the tree build."""
@@ -267,13 +278,18 @@ def run_grid512(job, tr):
     model, state, dataset = tr["model"], tr["state"], tr["dataset"]
     comm = job.comm()
     reso, center, radius = 512, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5]
-    state.repack(need_bwd=False)
+    if model.cfg.mlp_precision == 0:
+        state.repack(need_bwd=False)
     extraction.grid_sigma(model, state, 64, center, radius, comm)       # warm-up (small grid)
     job.sync()
     t0 = time.perf_counter()
     sig = extraction.grid_sigma(model, state, reso, center, radius, comm)
     job.sync()
     t_grid = job.max_over_ranks(time.perf_counter() - t0)
+    if stages_after_grid is False:
+        del sig
+        tflops = reso ** 3 * FLOP_SIGMA_PER_POINT / t_grid / 1e12
+        return {"points": reso ** 3, "grid_ms": 1e3 * t_grid, "equivalent_f32_tflops": tflops}
     tree = N3Tree(N=2, data_dim=1 + 3 * (tr["deg"] + 1) ** 2, init_refine=0, depth_limit=8, radius=radius,
                   center=center, data_format=f"SH{(tr['deg'] + 1) ** 2}", map_location=job.device)
     t0 = time.perf_counter()
@@ -321,6 +337,15 @@ def main():
     if not a.no_extras:
         extras["render_fwd"] = run_render(job, tr)
         extras["grid512"] = run_grid512(job, tr)
+        # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
+        twin = split_precision_twin(tr)
+        r3, g3 = run_render(job, twin), run_grid512(job, twin, stages_after_grid=False)
+        extras["opt_in_bf16x3_inference"] = {
+            "note": "PxoCfg.mlp_precision = bf16x3: forward-only, |dPSNR| vs the f64 oracle <= 1e-4 dB (tests/test_gpu_x3.py); "
+                    "training and the headline stay float32",
+            "render_fwd_rays_per_s": r3["value"], "render_fwd_ms_per_call": r3["ms_per_call"],
+            "grid512_ms": g3["grid_ms"], "grid512_equivalent_f32_tflops": g3["equivalent_f32_tflops"]}
+        twin = None
         other = "tt" if a.preset == "blender" else "blender"
         tr["state"] = tr["dataset"] = None          # release the headline workspace before the second preset
         torch.cuda.empty_cache()

@@ -58,7 +58,16 @@ typedef struct PxoCfg {
   float sparsity_length;       /* 0.05 */
   float sparsity_radius;       /* 1.5 */
   float weight_decay_mult;     /* 0 */
+  int32_t mlp_precision;       /* PXO_MLP_F32 (0, default) or PXO_MLP_BF16X3: INFERENCE-ONLY opt-in, see below */
 } PxoCfg;
+
+/* PxoCfg.mlp_precision.  PXO_MLP_F32: exact float32 MFMA everywhere (the reference's precision; training and every
+ * reported throughput use it).  PXO_MLP_BF16X3: the forward-only entry points (pxo_eval_points, pxo_grid_sigma,
+ * pxo_render_fwd, pxo_mlp_fwd without saved tensors) evaluate each product as hi*hi + hi*lo + lo*hi of bf16 splits with
+ * float32 accumulation (csrc/mlp_x3_kernels.hip); pxo_pack_weights then writes the split image (same size) and takes
+ * packed_bwd == NULL; pxo_train_fwd_bwd and the saved-tensor form of pxo_mlp_fwd return PXO_ERR_UNSUPPORTED. */
+#define PXO_MLP_F32 0
+#define PXO_MLP_BF16X3 1
 
 /* One leaf of the parameter arena (offsets in floats, relative to ONE MLP's sub-arena). */
 typedef struct PxoLeaf {

@@ -16,6 +16,7 @@ NET_WIDTH = 256
 ENC_DIM = 63
 ENC_PAD = 64
 NUM_LEAVES = 20
+MLP_F32, MLP_BF16X3 = 0, 1
 
 
 class PxoError(RuntimeError):
@@ -38,6 +39,7 @@ class PxoCfg(Structure):
         ("sparsity_length", c_float),
         ("sparsity_radius", c_float),
         ("weight_decay_mult", c_float),
+        ("mlp_precision", c_int32),
     ]
 
 
@@ -164,7 +166,8 @@ def make_cfg(**kw):
     """PxoCfg with the defaults of nerf_sh/config/blender.yaml over nerf_sh/nerf/utils.py:61-230."""
     vals = dict(num_coarse_samples=64, num_fine_samples=128, sh_deg=3, min_deg_point=0, max_deg_point=10,
                 white_bkgd=1, lindisp=0, sparsity_npoints=10000, near_=2.0, far_=6.0,
-                sparsity_weight=1e-3, sparsity_length=0.05, sparsity_radius=1.5, weight_decay_mult=0.0)
+                sparsity_weight=1e-3, sparsity_length=0.05, sparsity_radius=1.5, weight_decay_mult=0.0,
+                mlp_precision=0)
     for k, v in kw.items():
         if k not in vals:
             raise ValueError(f"unknown PxoCfg field {k}")

@@ -92,6 +92,10 @@ __global__ void pack_bwd_kernel(const float* __restrict__ p, int deg, float* __r
 }
 
 int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X3) {
+    if (bwd) { set_error("pack_weights: mlp_precision bf16x3 is forward-only (packed_bwd must be NULL)"); return PXO_ERR_UNSUPPORTED; }
+    return launch_pack_x3(cfg, mlp_params, fwd, s);
+  }
   hipLaunchKernelGGL(pack_fwd_kernel, dim3(512), dim3(256), 0, s, mlp_params, cfg->sh_deg, fwd);
   if (bwd) hipLaunchKernelGGL(pack_bwd_kernel, dim3(512), dim3(256), 0, s, mlp_params, cfg->sh_deg, bwd);
   return check_launch("pack_weights");
@@ -500,6 +504,10 @@ static int launch_fwd_any(const PxoCfg* cfg, const float* pk, const float* pts, 
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
                    float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
                    hipStream_t s) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X3) {
+    if (acts || enc || mask) { set_error("mlp_fwd: mlp_precision bf16x3 is inference-only (no saved tensors)"); return PXO_ERR_UNSUPPORTED; }
+    return launch_mlp_fwd_x3(cfg, packed_fwd, pts, 0, 0, nullptr, nullptr, M, raw_rgb, raw_sigma, s);
+  }
   GridSpec g;
   g.enabled = 0; g.reso = 1; g.x0 = 0;
   for (int i = 0; i < 3; ++i) { g.off[i] = 0.f; g.scale[i] = 1.f; }
@@ -508,6 +516,9 @@ int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts,
 
 int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
                         const float* off, const float* scale, float* sigma_out, hipStream_t s) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X3)
+    return launch_mlp_fwd_x3(cfg, packed_fwd, nullptr, reso, x0, off, scale, (int64_t)(x1 - x0) * reso * reso, nullptr,
+                             sigma_out, s);
   GridSpec g;
   g.enabled = 1; g.reso = reso; g.x0 = x0;
   for (int i = 0; i < 3; ++i) { g.off[i] = off[i]; g.scale[i] = scale[i]; }

@@ -1,0 +1,345 @@
+// Opt-in split-precision forward of the NeRF-SH MLP for gfx950: PxoCfg.mlp_precision = PXO_MLP_BF16X3.
+//
+// INFERENCE ONLY (pxo_eval_points / pxo_grid_sigma / pxo_render_fwd / pxo_mlp_fwd without saved tensors): the
+// training path and every headline number stay on the exact-f32 kernels of mlp_kernels.hip.
+//
+// Every f32 operand x is split as x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi) (round to nearest
+// even, v_cvt_pk_bf16_f32), and a product is evaluated as  hi_a hi_b + hi_a lo_b + lo_a hi_b  -- three
+// v_mfma_f32_32x32x16_bf16 with float32 accumulation (bf16 x bf16 products are exact in f32; the dropped lo_a lo_b term
+// is 2^-16 relative).  The bf16 MFMA runs at 16x the f32 MFMA rate, so the three passes cost 3/16 of the f32 GEMM.
+// Measured against the float64 oracle the rendered colours differ by |dPSNR| ~ 2e-5 dB (the bar of north_star is
+// 1e-4 dB; tests/test_gpu_x3.py), i.e. as close to float64 as the float32 evaluation is.
+//
+// Replaces posenc + MLP.__call__ (nerf_sh/nerf/model_utils.py:43-94,145-173; torch twin
+// octree/nerf/model_utils.py:87-158) for the same configurations as mlp_fwd_kernel.
+//
+// Data flow (same persistent-tile structure as mlp_fwd_kernel, different operand plumbing):
+//  * the 128-row activation tile lives in LDS as TWO bf16 planes (hi, lo), row stride 264 bf16 = 528 B (conflict-free
+//    ds_read_b128 / ds_write_b64); same 132 KB footprint as the f32 tile;
+//  * weights are pre-split and packed per (16-wide k-group, 32-column block) as [hi | lo] fragments of 64 lanes x
+//    16 B, read straight from L2 into registers three k-groups ahead (image size and layer offsets are those of
+//    the f32 image: 4 bytes per weight either way);
+//  * the product is computed TRANSPOSED (weights as the A operand, activations as B): a lane then owns 4 consecutive
+//    output features of one sample per register quad, so the epilogue (bias, ReLU, split) packs 4 bf16 and writes
+//    one ds_write_b64 per plane instead of 8 scattered 2-byte writes.
+#include "pxo_common.h"
+
+namespace pxo {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLDB = 264;                    // LDS row stride in bf16 (256 + 8: one b128 access of pad)
+constexpr int kX3Waves = kMlpThreads / 64;   // 8
+
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: element e of lane l in block (kg, cb, part) = part(W[k = 16 kg + 8 (l >> 5) + e][n = 32 cb + (l & 31)])
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float x3_src_weight(const float* __restrict__ p, int deg, int l, int k, int n) {
+  const int C = rgb_channels(deg);
+  if (l < 8) {
+    if (k >= layer_in(l) || n >= kW) return 0.f;
+    return p[leaf_kernel_off(l, deg) + (int64_t)k * kW + n];
+  }
+  if (k >= kW) return 0.f;
+  if (n < C) return p[leaf_kernel_off(9, deg) + (int64_t)k * C + n];
+  if (n == C) return p[leaf_kernel_off(8, deg) + k];
+  return 0.f;
+}
+
+__global__ void pack_fwd_x3_kernel(const float* __restrict__ p, int deg, float* __restrict__ out) {
+  const int nhb = head_blocks(deg);
+  const int64_t total = fwd_image_floats(deg);
+  const int64_t bias_off = fwd_bias_off(deg);
+  // one thread per 4-byte slot: below bias_off a slot holds two bf16 (elements 2s, 2s+1 of a 16-byte lane fragment)
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx >= bias_off) {
+      const int b = (int)(idx - bias_off);
+      float v;
+      if (b < 8 * kW) {
+        v = p[leaf_bias_off(b / kW, deg) + (b % kW)];
+      } else {
+        const int n = b - 8 * kW, C = rgb_channels(deg);
+        v = n < C ? p[leaf_bias_off(9, deg) + n] : (n == C ? p[leaf_bias_off(8, deg)] : 0.f);
+      }
+      out[idx] = v;
+      continue;
+    }
+    int l = 0;
+    while (l < 8 && idx >= fwd_layer_off(l + 1)) ++l;
+    const int64_t loc = idx - fwd_layer_off(l);          // in 4-byte slots
+    const int ncb = l < 8 ? 8 : nhb;
+    const int s = (int)(loc & 3), lane = (int)((loc >> 2) & 63);
+    const int64_t blk = loc >> 8;                        // (kg, cb, part): 64 lanes x 4 slots = 256 slots per block
+    const int part = (int)(blk & 1);
+    const int64_t kc = blk >> 1;
+    const int cb = (int)(kc % ncb), kg = (int)(kc / ncb);
+    const int n = 32 * cb + (lane & 31);
+    __bf16 pair[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = 16 * kg + 8 * (lane >> 5) + 2 * s + j;
+      __bf16 hi, lo;
+      split_bf16(x3_src_weight(p, deg, l, k, n), hi, lo);
+      pair[j] = part == 0 ? hi : lo;
+    }
+    uint32_t bits;
+    __builtin_memcpy(&bits, pair, 4);
+    reinterpret_cast<uint32_t*>(out)[idx] = bits;
+  }
+}
+
+int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipStream_t s) {
+  hipLaunchKernelGGL(pack_fwd_x3_kernel, dim3(512), dim3(256), 0, s, mlp_params, cfg->sh_deg, fwd);
+  return check_launch("pack_weights(bf16x3)");
+}
+
+// ------------------------------------------------------------------------------------------
+// the tile GEMM: acc[rb] (32 features x 32 samples, transposed) += W^T[features, K] X^T[K, samples of row block rb]
+// ------------------------------------------------------------------------------------------
+struct X3Frag { bf16x8 hi, lo; };
+
+__device__ __forceinline__ X3Frag load_w(const f32x4* __restrict__ wp, int kg, int kg_stride) {
+  X3Frag f;
+  const f32x4 h = wp[(int64_t)kg * kg_stride], l = wp[(int64_t)kg * kg_stride + 64];
+  __builtin_memcpy(&f.hi, &h, 16);
+  __builtin_memcpy(&f.lo, &l, 16);
+  return f;
+}
+
+template <int RBN>
+__device__ __forceinline__ void load_x(const __bf16* __restrict__ xh, const __bf16* __restrict__ xl, int kg, X3Frag (&x)[RBN]) {
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) {
+    x[r].hi = *reinterpret_cast<const bf16x8*>(xh + r * 32 * kLDB + kg * 16);
+    x[r].lo = *reinterpret_cast<const bf16x8*>(xl + r * 32 * kLDB + kg * 16);
+  }
+}
+
+template <int RBN>
+__device__ __forceinline__ void mfma3(const X3Frag& w, const X3Frag (&x)[RBN], f32x16 (&acc)[RBN]) {
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x[r].hi, acc[r], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x[r].lo, acc[r], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x[r].hi, acc[r], 0, 0, 0);
+}
+
+// weights (L2 latency) three k-groups ahead in four rotating register sets, activations (LDS) one ahead in two;
+// kgroups must be a multiple of 4.  xh / xl: this lane's row (lane & 31) and k offset 8 (lane >> 5) inside the planes.
+#define PXO_X3_PIN() __builtin_amdgcn_sched_barrier(0)
+template <int RBN>
+__device__ __forceinline__ void gemm_x3(const __bf16* __restrict__ xh, const __bf16* __restrict__ xl,
+                                        const f32x4* __restrict__ wp, int kgroups, int kg_stride, f32x16 (&acc)[RBN]) {
+  X3Frag w[4], x0[RBN], x1[RBN];
+  const int last = kgroups - 1;
+  auto cl = [&](int g) { return g < last ? g : last; };
+#pragma unroll
+  for (int i = 0; i < 3; ++i) w[i] = load_w(wp, cl(i), kg_stride);
+  load_x<RBN>(xh, xl, 0, x0);
+  for (int g = 0; g < kgroups; g += 4) {
+    load_x<RBN>(xh, xl, g + 1, x1);
+    w[3] = load_w(wp, cl(g + 3), kg_stride);
+    PXO_X3_PIN();
+    mfma3<RBN>(w[0], x0, acc);
+    PXO_X3_PIN();
+    load_x<RBN>(xh, xl, g + 2, x0);
+    w[0] = load_w(wp, cl(g + 4), kg_stride);
+    PXO_X3_PIN();
+    mfma3<RBN>(w[1], x1, acc);
+    PXO_X3_PIN();
+    load_x<RBN>(xh, xl, g + 3, x1);
+    w[1] = load_w(wp, cl(g + 5), kg_stride);
+    PXO_X3_PIN();
+    mfma3<RBN>(w[2], x0, acc);
+    PXO_X3_PIN();
+    load_x<RBN>(xh, xl, cl(g + 4), x0);
+    w[2] = load_w(wp, cl(g + 6), kg_stride);
+    PXO_X3_PIN();
+    mfma3<RBN>(w[3], x1, acc);
+    PXO_X3_PIN();
+  }
+}
+
+// dense-grid point source (same formula as mlp_kernels.hip; octree/extraction.py:290-303)
+struct X3Grid {
+  int enabled, reso, x0;
+  float off[3], scale[3];
+};
+
+__device__ __forceinline__ float x3_enc_value(float p0, float p1, float p2, int col) {
+  if (col < 3) return col == 0 ? p0 : (col == 1 ? p1 : p2);
+  if (col >= kEnc) return 0.f;
+  int idx = col - 3;
+  const bool shifted = idx >= 30;
+  if (shifted) idx -= 30;
+  const int l = idx / 3, a = idx - 3 * l;
+  float xb = (a == 0 ? p0 : (a == 1 ? p1 : p2)) * (float)(1 << l);
+  if (shifted) xb = xb + 1.5707963267948966f;
+  return sinf(xb);
+}
+
+// posenc of the tile's 128 points, split, into planes[:, 0:64]
+__device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* __restrict__ pl, const float* __restrict__ pts,
+                                               const X3Grid& grid, int64_t row0, int64_t M, int tid) {
+  const int row = tid % kTM, part = tid / kTM;          // 4 parts x 16 columns
+  const int64_t grow = row0 + row;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+  if (grow < M) {
+    if (grid.enabled) {
+      const int r = grid.reso;
+      const int iz = (int)(grow % r);
+      const int64_t t = grow / r;
+      const int iy = (int)(t % r), ix = (int)(t / r) + grid.x0;
+      p0 = ((((float)ix + 0.5f) / (float)r) - grid.off[0]) / grid.scale[0];
+      p1 = ((((float)iy + 0.5f) / (float)r) - grid.off[1]) / grid.scale[1];
+      p2 = ((((float)iz + 0.5f) / (float)r) - grid.off[2]) / grid.scale[2];
+    } else {
+      p0 = pts[grow * 3]; p1 = pts[grow * 3 + 1]; p2 = pts[grow * 3 + 2];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __bf16 a, b;
+      split_bf16(x3_enc_value(p0, p1, p2, part * 16 + h * 8 + i), a, b);
+      vh[i] = a; vl[i] = b;
+    }
+    *reinterpret_cast<bf16x8*>(ph + row * kLDB + part * 16 + h * 8) = vh;
+    *reinterpret_cast<bf16x8*>(pl + row * kLDB + part * 16 + h * 8) = vl;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int NHB, bool RGB>
+__global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_x3_kernel(
+    const float* __restrict__ pk, const float* __restrict__ pts, X3Grid grid, int64_t M, int deg,
+    float* __restrict__ raw_rgb, float* __restrict__ raw_sigma) {
+  __shared__ __attribute__((aligned(16))) __bf16 plane_h[kTM * kLDB];
+  __shared__ __attribute__((aligned(16))) __bf16 plane_l[kTM * kLDB];
+  constexpr int kRB = kTM / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = rgb_channels(deg);
+  const float* __restrict__ bias = pk + fwd_bias_off(deg);
+  // this lane's operand position: sample row (lane & 31) of a row block, k offset 8 (lane >> 5) of a k-group
+  const __bf16* xh = plane_h + (lane & 31) * kLDB + (lane >> 5) * 8;
+  const __bf16* xl = plane_l + (lane & 31) * kLDB + (lane >> 5) * 8;
+  const int64_t ntiles = num_tiles(M);
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kTM;
+    __syncthreads();   // previous tile's head GEMM has consumed the planes
+    posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
+    __syncthreads();
+
+    f32x16 acc[kRB];
+    for (int l = 0; l < kDepth; ++l) {
+#pragma unroll
+      for (int r = 0; r < kRB; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+      // fragments of this wave's 32 output features: (kg, cb = wave, part) blocks, 2 x 64 f32x4 per (kg, cb)
+      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (int64_t)wave * 128 + lane;
+      gemm_x3<kRB>(xh, xl, wp, l == 0 ? 4 : 16, 8 * 128, acc);
+      if (l == 5) {
+        // skip connection (model_utils.py:70-71): the 64 encoded columns are a second K segment, recomputed in place
+        __syncthreads();
+        posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
+        __syncthreads();
+        gemm_x3<kRB>(xh, xl, wp + (int64_t)16 * 8 * 128, 4, 8 * 128, acc);
+      }
+      __syncthreads();  // every wave has consumed the input planes
+      // epilogue: lane holds features n0 .. n0+3 of sample m per register quad
+#pragma unroll
+      for (int r = 0; r < kRB; ++r) {
+        const int m = r * 32 + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + l * kW + n0);
+          bf16x4 vh, vl;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            __bf16 a, b;
+            split_bf16(fmaxf(acc[r][4 * q + t] + b4[t], 0.f), a, b);
+            vh[t] = a; vl[t] = b;
+          }
+          *reinterpret_cast<bf16x4*>(plane_h + m * kLDB + n0) = vh;
+          *reinterpret_cast<bf16x4*>(plane_l + m * kLDB + n0) = vl;
+        }
+      }
+      __syncthreads();
+    }
+
+    // heads (model_utils.py:72-74, :91-93): wave w owns row block w % 4 and head blocks w / 4, w / 4 + 2, ...;
+    // sigma only (RGB = false): the block that holds column C
+    {
+      constexpr int CSTEP = kX3Waves / kRB;               // 2 waves per row block
+      constexpr int HMAX = RGB ? (NHB + CSTEP - 1) / CSTEP : 1;
+      const int rb = wave % kRB, cb0 = wave / kRB;
+      const float* hb = bias + 8 * kW;
+#pragma unroll 1
+      for (int i = 0; i < HMAX; ++i) {
+        const int cb = RGB ? cb0 + i * CSTEP : (cb0 == 0 ? NHB - 1 : NHB);
+        if (cb >= NHB) continue;                           // wave-uniform
+        f32x16 hacc[1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hacc[0][j] = 0.f;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + (int64_t)cb * 128 + lane;
+        gemm_x3<1>(xh + rb * 32 * kLDB, xl + rb * 32 * kLDB, wp, 16, NHB * 128, hacc);
+        const int64_t grow = row0 + rb * 32 + (lane & 31);
+        if (grow < M) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int col = cb * 32 + 8 * q + 4 * (lane >> 5) + t;
+              const float v = hacc[0][4 * q + t] + hb[col];
+              if (col < C) { if (RGB) raw_rgb[grow * C + col] = v; }
+              else if (col == C) raw_sigma[grow] = v;
+            }
+        }
+      }
+    }
+  }
+}
+
+template <int NHB>
+static int launch_x3_nhb(const PxoCfg* cfg, const float* pk, const float* pts, const X3Grid& grid, int64_t M,
+                         float* raw_rgb, float* raw_sigma, hipStream_t s) {
+  KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
+  const int64_t tiles = num_tiles(M), cap = num_cus();
+  dim3 grid_dim((unsigned)(tiles < cap ? tiles : cap)), block(kMlpThreads);
+  if (raw_rgb)
+    hipLaunchKernelGGL((mlp_fwd_x3_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma);
+  else
+    hipLaunchKernelGGL((mlp_fwd_x3_kernel<NHB, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma);
+  return check_launch("mlp_fwd(bf16x3)");
+}
+
+int launch_mlp_fwd_x3(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int reso, int x0,
+                      const float* off, const float* scale, int64_t M, float* raw_rgb, float* raw_sigma, hipStream_t s) {
+  if (M == 0) return PXO_OK;
+  X3Grid g;
+  g.enabled = pts == nullptr; g.reso = reso > 0 ? reso : 1; g.x0 = x0;
+  for (int i = 0; i < 3; ++i) { g.off[i] = off ? off[i] : 0.f; g.scale[i] = scale ? scale[i] : 1.f; }
+  switch (head_blocks(cfg->sh_deg)) {
+    case 1: return launch_x3_nhb<1>(cfg, packed_fwd, pts, g, M, raw_rgb, raw_sigma, s);
+    case 2: return launch_x3_nhb<2>(cfg, packed_fwd, pts, g, M, raw_rgb, raw_sigma, s);
+    default: return launch_x3_nhb<3>(cfg, packed_fwd, pts, g, M, raw_rgb, raw_sigma, s);
+  }
+}
+
+}  // namespace pxo

@@ -52,6 +52,8 @@ int validate_cfg(const PxoCfg* cfg) {
               cfg->num_coarse_samples);
   PXO_REQUIRE(cfg->num_fine_samples >= 0 && cfg->num_coarse_samples + cfg->num_fine_samples <= 256,
               "num_coarse_samples+num_fine_samples must be <= 256");
+  PXO_REQUIRE(cfg->mlp_precision == PXO_MLP_F32 || cfg->mlp_precision == PXO_MLP_BF16X3, "mlp_precision %d unknown",
+              cfg->mlp_precision);
   return PXO_OK;
 }
 
@@ -410,6 +412,10 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   PXO_REQUIRE(B >= 1 && params && packed_fwd0 && packed_bwd0 && origins && directions && viewdirs && pixels && grads &&
                   stats && ws,
               "pxo_train_fwd_bwd: bad arguments");
+  if (cfg->mlp_precision != PXO_MLP_F32) {
+    set_error("pxo_train_fwd_bwd: training runs in float32 only (mlp_precision must be PXO_MLP_F32)");
+    return PXO_ERR_UNSUPPORTED;
+  }
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   if (Nf > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
   hipStream_t s = (hipStream_t)stream;

@@ -158,6 +158,10 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
                            size_t ws_bytes, hipStream_t s);
 int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
+// opt-in split-precision forward (mlp_x3_kernels.hip); pts == nullptr selects the dense-grid point source
+int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipStream_t s);
+int launch_mlp_fwd_x3(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int reso, int x0, const float* off,
+                      const float* scale, int64_t M, float* raw_rgb, float* raw_sigma, hipStream_t s);
 
 int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_,
                              float far_, int lindisp, const float* t_rand, float* z, float* pts,

@@ -38,6 +38,7 @@ class TrainState:
 
     def repack(self, need_bwd=True):
         """Refresh the fragment-ordered images after a parameter update."""
+        need_bwd = need_bwd and self.cfg.mlp_precision == 0      # the split-precision images are forward-only
         for i in range(2):
             f, b = self.packed[i] if self.packed[i] is not None else (None, None)
             self.packed[i] = ops.pack_weights(self.cfg, self.mlp_params(i), f, b, need_bwd=need_bwd)
@@ -98,7 +99,8 @@ def make_cfg(args):
                         white_bkgd=int(args.white_bkgd), lindisp=int(args.lindisp),
                         sparsity_npoints=args.sparsity_npoints, near_=args.near, far_=args.far,
                         sparsity_weight=args.sparsity_weight, sparsity_length=args.sparsity_length,
-                        sparsity_radius=args.sparsity_radius, weight_decay_mult=args.weight_decay_mult)
+                        sparsity_radius=args.sparsity_radius, weight_decay_mult=args.weight_decay_mult,
+                        mlp_precision=1 if getattr(args, "mlp_precision", "f32") == "bf16x3" else 0)
 
 
 def construct_nerf(args, device, seed=None):

@@ -46,6 +46,9 @@ def define_flags(parser=None):
     a("--net_depth", type=int, default=8)
     a("--net_width", type=int, default=256)
     a("--weight_decay_mult", type=float, default=0.0)
+    # not a reference flag: opt-in split-precision MLP forward for the inference entry points (eval, gen_video, extraction);
+    # training is float32 regardless
+    a("--mlp_precision", type=str, default="f32", choices=["f32", "bf16x3"])
     a("--skip_layer", type=int, default=4)
     a("--num_rgb_channels", type=int, default=3)
     a("--num_sigma_channels", type=int, default=1)

@@ -22,6 +22,8 @@ def main(argv=None):
     torch.cuda.set_device(comm.local_rank)
     device = torch.device("cuda", comm.local_rank)
     utils.check_flags(args, require_batch_size_div=True, world_size=comm.world)
+    if args.mlp_precision != "f32":
+        raise ValueError("--mlp_precision bf16x3 is an inference option (eval / gen_video / extraction); training runs in float32")
     h0 = comm.rank == 0
     if h0:
         os.makedirs(args.train_dir, exist_ok=True)

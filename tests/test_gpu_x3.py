@@ -1,0 +1,113 @@
+"""Opt-in split-precision forward (PxoCfg.mlp_precision = bf16x3, csrc/mlp_x3_kernels.hip) against the float64 oracle.
+
+Every product of the MLP is evaluated as hi*hi + hi*lo + lo*hi of bf16 splits with float32 accumulation -- 3/16 of the
+float32 MFMA time.  It is INFERENCE-ONLY and never the reported throughput; what is shown here is that it stays inside
+the north_star bar |dPSNR| <= 1e-4 dB, i.e. that it is as close to float64 as the float32 evaluation is to within a
+small factor:
+  raw MLP outputs      error vs float64 <= 6 x the float32 kernel's error (+ 2e-6 absolute)
+  rendered colours     |dPSNR| <= 1e-4 dB vs the f64 oracle at 4096 rays, image PSNR vs f64 >= 70 dB
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from _helpers import _gpu, _ops, _psnr, close, make_params, make_rays, oracle_render_chunked, pxo_cfg, split_mlp
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(ops, cfg):
+    c32 = pxo_cfg(ops, cfg)
+    cx3 = pxo_cfg(ops, cfg)
+    cx3.mlp_precision = 1
+    return c32, cx3
+
+
+@pytest.mark.parametrize("deg,N", [(3, 5000), (4, 777), (0, 129), (3, 1)])
+def test_eval_points_x3_vs_f64(deg, N):
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg)
+    c32, cx3 = _cfgs(ops, cfg)
+    flat = make_params(cfg, bias_scale=0.2)
+    mlp = split_mlp(flat, cfg, 1).to(dev)
+    p32, _ = ops.pack_weights(c32, mlp, need_bwd=False)
+    px3, _ = ops.pack_weights(cx3, mlp, need_bwd=False)
+    assert p32.numel() == px3.numel()                       # same image size: 4 bytes per weight either way
+    pts = ((torch.rand(N, 3, generator=torch.Generator().manual_seed(N)) * 2 - 1) * 2.0)
+    with torch.no_grad():
+        r64, s64 = O.eval_points_raw(O.unflatten_params(flat.double(), cfg), pts.double(), cfg)
+    out = {}
+    for tag, c, p in (("f32", c32, p32), ("x3", cx3, px3)):
+        rgb, sig = ops.eval_points(c, p, pts.to(dev))
+        _, sig_only = ops.eval_points(c, p, pts.to(dev), want_rgb=False)
+        assert torch.equal(sig, sig_only)
+        out[tag] = (float((rgb.cpu().double() - r64).abs().max()), float((sig.cpu().double() - s64).abs().max()),
+                    float((rgb.cpu().double() - r64).abs().mean()))
+    scale = float(r64.abs().max())
+    for j in range(3):
+        assert out["x3"][j] <= 6 * out["f32"][j] + 2e-6 * max(scale, 1.0), (out, scale)
+    assert out["x3"][0] <= 3e-4 * max(scale, 1.0)           # and small in absolute terms
+
+
+def test_x3_is_forward_only():
+    ops = _ops(); dev = _gpu()
+    from plenoctree_amd import _lib
+    cfg = O.Cfg(); _, cx3 = _cfgs(ops, cfg)
+    flat = make_params(cfg).to(dev)
+    with pytest.raises(_lib.PxoError, match="forward-only"):
+        ops.pack_weights(cx3, split_mlp(flat, cfg, 0), need_bwd=True)
+    pf, _ = ops.pack_weights(cx3, split_mlp(flat, cfg, 0), need_bwd=False)
+    with pytest.raises(_lib.PxoError, match="inference-only"):
+        ops.mlp_fwd(cx3, pf, torch.zeros(64, 3, device=dev), save=True)
+    packed = [(pf, pf), (pf, pf)]
+    with pytest.raises(_lib.PxoError, match="float32 only"):
+        ops.train_fwd_bwd(cx3, flat, packed, torch.zeros(8, 3, device=dev), torch.ones(8, 3, device=dev),
+                          torch.ones(8, 3, device=dev), torch.zeros(8, 3, device=dev), torch.zeros_like(flat),
+                          torch.zeros(6, device=dev), torch.empty(1 << 20, dtype=torch.uint8, device=dev))
+
+
+@pytest.mark.parametrize("preset", ["blender", "tt"])
+def test_render_fwd_x3_full_batch(preset):
+    """pxo_render_fwd with the split-precision MLPs on 4096 rays: |dPSNR| <= 1e-4 dB against the float64 oracle."""
+    ops = _ops(); dev = _gpu()
+    kw = dict(blender=dict(sh_deg=3), tt=dict(sh_deg=4, near=0.0, far=4.0))[preset]
+    cfg = O.Cfg(**kw)
+    c32, cx3 = _cfgs(ops, cfg)
+    flat = make_params(cfg, bias_scale=0.2)
+    B = 4096
+    rays = make_rays(B, 141)
+    if preset == "tt":
+        rays = O.Rays(rays.origins * 0.5, rays.directions, rays.viewdirs)
+    gen = torch.Generator().manual_seed(143)
+    t_rand = torch.rand(B, 64, generator=gen); u = torch.rand(B, 128, generator=gen)
+    target = torch.rand(B, 3, generator=gen)
+    torch.set_num_threads(32)
+    ref64 = oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float64)
+    res = {}
+    for tag, c in (("f32", c32), ("x3", cx3)):
+        pk = [ops.pack_weights(c, split_mlp(flat, cfg, i).to(dev), need_bwd=False)[0] for i in range(2)]
+        out = ops.render_fwd(c, pk[0], pk[1], rays.origins.to(dev), rays.directions.to(dev), rays.viewdirs.to(dev),
+                             randomized=True, t_rand=t_rand.to(dev), u=u.to(dev))
+        res[tag] = [lvl[0].cpu() for lvl in out]
+    for lvl in (0, 1):
+        d = abs(_psnr(res["x3"][lvl], target) - _psnr(ref64[lvl][0], target))
+        assert d <= 1e-4, (preset, lvl, d)
+        assert _psnr(res["x3"][lvl], ref64[lvl][0]) >= 70.0
+    # coarse level (no resampling involved): element-wise close to float64
+    close("coarse rgb", res["x3"][0], ref64[0][0].float(), rtol=0, atol=5e-5)
+
+
+def test_grid_sigma_x3():
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(); c32, cx3 = _cfgs(ops, cfg)
+    flat = make_params(cfg, bias_scale=0.2)
+    mlp = split_mlp(flat, cfg, 1).to(dev)
+    p32, _ = ops.pack_weights(c32, mlp, need_bwd=False)
+    px3, _ = ops.pack_weights(cx3, mlp, need_bwd=False)
+    off, sc = [0.5, 0.5, 0.5], [1 / 3.0] * 3
+    a = ops.grid_sigma(c32, p32, 64, 0, 64, off, sc)
+    b = ops.grid_sigma(cx3, px3, 64, 0, 64, off, sc)
+    close("grid sigma x3 vs f32", b, a, rtol=2e-4, atol=2e-4)
+    part = ops.grid_sigma(cx3, px3, 64, 16, 32, off, sc)
+    assert torch.equal(part, b[16 * 64 * 64:32 * 64 * 64])

@@ -569,6 +569,12 @@ def test_cli_train_eval_extraction(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_60"))
     psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0
+    # the same evaluation with the opt-in split-precision MLP forward: the same PSNR to well inside 1e-3 dB
+    psnrs_x3 = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false",
+                                        "--mlp_precision", "bf16x3"])
+    assert max(abs(a - b) for a, b in zip(psnrs, psnrs_x3)) < 1e-3, (psnrs, psnrs_x3)
+    with pytest.raises(ValueError, match="inference option"):
+        train.main(common + ["--mlp_precision", "bf16x3"])
     from plenoctree_amd.nerf_sh import gen_video
     frames = gen_video.main(common + ["--num_views", "2", "--height", "20", "--width", "24", "--chunk", "256",
                                       "--write_poses", os.path.join(str(tmp_path), "poses.txt")])

@@ -4,7 +4,7 @@ Every product of the MLP is evaluated as hi*hi + hi*lo + lo*hi of bf16 splits wi
 float32 MFMA time.  It is INFERENCE-ONLY and never the reported throughput; what is shown here is that it stays inside
 the north_star bar |dPSNR| <= 1e-4 dB, i.e. that it is as close to float64 as the float32 evaluation is to within a
 small factor:
-  raw MLP outputs      error vs float64 <= 12 x the float32 kernel's error (measured 7-8 x: ~1e-5 on values of order 1)
+  raw MLP outputs      max error vs float64 <= 5e-5 x output scale; mean error <= 12 x the float32 kernel's (measured 7-8 x)
   rendered colours     |dPSNR| <= 1e-4 dB vs the f64 oracle at 4096 rays, image PSNR vs f64 >= 70 dB
 """
 import numpy as np
@@ -44,10 +44,11 @@ def test_eval_points_x3_vs_f64(deg, N):
         assert torch.equal(sig, sig_only)
         out[tag] = (float((rgb.cpu().double() - r64).abs().max()), float((sig.cpu().double() - s64).abs().max()),
                     float((rgb.cpu().double() - r64).abs().mean()))
-    scale = float(r64.abs().max())
-    for j in range(3):
-        assert out["x3"][j] <= 12 * out["f32"][j] + 2e-6 * max(scale, 1.0), (out, scale)
-    assert out["x3"][0] <= 3e-4 * max(scale, 1.0)           # and small in absolute terms
+    s_rgb, s_sig = max(float(r64.abs().max()), 1.0), max(float(s64.abs().max()), 1.0)
+    # fixed bounds relative to the output scale (measured: rgb 1.1e-5 on values up to 1.4, sigma 7e-5 on values up to ~15)
+    assert out["x3"][0] <= 5e-5 * s_rgb and out["x3"][1] <= 5e-5 * s_sig, (out, s_rgb, s_sig)
+    if N >= 100:            # and, on average, within an order of magnitude of the float32 kernel (measured 7-8 x)
+        assert out["x3"][2] <= 12 * out["f32"][2] + 1e-7, out
 
 
 def test_x3_is_forward_only():

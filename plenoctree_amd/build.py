@@ -93,6 +93,8 @@ if __name__ == "__main__":
         build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
     if "--variants2" in sys.argv:
         build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
+    if "--trace" in sys.argv:      # cycle-stamped wgrad kernel (timing experiment)
+        build(suffix="_wtrace", extra_flags=("-DPXO_TRACE_WGRAD",))
     if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)
         build(suffix="_abl_nostore", extra_flags=("-DPXO_ABLATE_STORE",))   # fused MLP kernels without the tile copy to HBM
     if "--wgrad-variants" in sys.argv:

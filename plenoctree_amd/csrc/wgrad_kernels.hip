@@ -16,6 +16,22 @@ constexpr int kKC = 32;           // row granularity of the split (rows_per_wg i
 #define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
 #endif
 
+#ifdef PXO_TRACE_WGRAD
+// cycle stamps of wave 0 of workgroup 0 over a few steady-state chunks (timing experiments only): kept in LDS while the
+// kernel runs (a stamp is s_memtime + ds_write, no wait), flushed at the end
+__device__ unsigned long long g_wtrace[2048];
+__device__ int g_wtrace_n;
+#define WTRACE(id)                                                                                         \
+  do {                                                                                                     \
+    if (KIN == 256 && NOUT == 256 && blockIdx.x == 0 && threadIdx.x == 0 && ch >= 40 && ch < 48 && s_tn < 250) { \
+      s_trace[s_tn] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFull); \
+      s_tn++;                                                                                              \
+    }                                                                                                      \
+  } while (0)
+#else
+#define WTRACE(id)
+#endif
+
 // Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over
 // NSPLIT workgroups (each owns NOUT/NSPLIT output columns and re-reads X; the NSPLIT partners of a
 // row range are placed 8 blocks apart = on the same XCD so the second read of X hits L2).
@@ -37,6 +53,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   __shared__ __attribute__((aligned(16))) float xs[2][KCH * KIN];
   __shared__ __attribute__((aligned(16))) float zs[2][KCH * NTILE];
 
+#ifdef PXO_TRACE_WGRAD
+  __shared__ unsigned long long s_trace[256];
+  int s_tn = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
@@ -54,22 +74,25 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   if (r_end > M) r_end = M;
   const int nchunks = (int)((r_end - r_begin + KCH - 1) / KCH);
 
-  f32x4 xr[XV];
-  f32x4 zr4[HEAD ? 1 : ZV];
-  float zr1[HEAD ? ZV : 1];
-
-  uint32_t okx = 0u, okz = 0u;   // per-thread validity bits of the rows held in xr / zr4
-  auto load_chunk = [&](int ch) {
+  // one staged chunk in registers: global -> registers -> LDS.  (Two stages, i.e. loads issued two chunk-times ahead
+  // of their LDS store, were built and measured 2.4 % SLOWER on the 256x256 product: 0.563 vs 0.550 ms.)
+  struct Stage {
+    f32x4 xr[XV];
+    f32x4 zr4[HEAD ? 1 : ZV];
+    float zr1[HEAD ? ZV : 1];
+    uint32_t okx, okz;           // per-thread validity bits of the rows held in xr / zr4
+  };
+  auto load_chunk = [&](int ch, Stage& st) {
     const int64_t r0 = r_begin + (int64_t)ch * KCH;
-    okx = 0u; okz = 0u;
+    st.okx = 0u; st.okz = 0u;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
       const int64_t grow = r0 + row;
       const bool ok = grow < r_end;                      // rows past the range contribute zeros:
-      okx |= (ok ? 1u : 0u) << i;                        // selected at store time, so that nothing
-      xr[i] = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);  // waits here
+      st.okx |= (ok ? 1u : 0u) << i;                     // selected at store time, so that nothing
+      st.xr[i] = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);  // waits here
     }
     if (HEAD) {
 #pragma unroll
@@ -82,7 +105,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
           if (col < C) v = dZ[grow * C + col];
           else if (col == C) v = d_raw_sigma[grow];
         }
-        zr1[i] = v;
+        st.zr1[i] = v;
       }
     } else {
 #pragma unroll
@@ -91,30 +114,30 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
         const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
         const int64_t grow = r0 + row;
         const bool ok = grow < r_end;
-        okz |= (ok ? 1u : 0u) << i;
+        st.okz |= (ok ? 1u : 0u) << i;
         if (DUAL) {
           const float* __restrict__ src = c4 * 4 < kW ? dZ : dZ2;
-          zr4[i] = *reinterpret_cast<const f32x4*>(src + (ok ? grow : r_begin) * kW + ((c4 * 4) & (kW - 1)));
+          st.zr4[i] = *reinterpret_cast<const f32x4*>(src + (ok ? grow : r_begin) * kW + ((c4 * 4) & (kW - 1)));
         } else {
-          zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
+          st.zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
         }
       }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const Stage& st) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + NT * i;
-      *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((okx >> i) & 1u) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((st.okx >> i) & 1u) ? st.xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (HEAD) {
 #pragma unroll
-      for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = zr1[i];
+      for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = st.zr1[i];
     } else {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
         const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((okz >> i) & 1u) ? zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((st.okz >> i) & 1u) ? st.zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -127,15 +150,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
 
-  if (nchunks > 0) {
-    load_chunk(0);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
-    const bool more = ch + 1 < nchunks;
-    if (SCHED == 0 && more) load_chunk(ch + 1);
+  // computes chunk `ch` out of LDS buffer `buf`; on the way: loads chunk `ld_ch` into `ld` (if do_ld) and stores the
+  // chunk held in `stg` into the other LDS buffer (if do_st)
+  auto run_chunk = [&](int ch, int buf, Stage& ld, int ld_ch, bool do_ld, const Stage& stg, bool do_st) {
+    (void)ch;
+    WTRACE(1);
+    if (SCHED == 0 && do_ld) load_chunk(ld_ch, ld);
+    WTRACE(2);
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
@@ -161,23 +182,48 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      // SCHED 1 (the skinny, HBM-heavy products; the 256x256 product measured 2 % slower with it):
-      // the next chunk's global loads (address arithmetic + 6 loads) are issued under the first MFMA group of this
-      // chunk, and its LDS stores under the last one: the stretch between a chunk's last MFMA and the next chunk's
-      // first is then only "barrier + first operand reads"
-      if (SCHED != 0 && kk == 0 && more) load_chunk(ch + 1);
+      WTRACE(10 + kk);
+      // SCHED 1 (the skinny, HBM-heavy products; the 256x256 product measured 2 % slower with it): the loads
+      // (address arithmetic + 6 loads) are issued under the first MFMA group of this chunk, the LDS stores under the
+      // last one: the stretch between a chunk's last MFMA and the next chunk's first is then only "barrier + first
+      // operand reads"
+      if (SCHED != 0 && kk == 0 && do_ld) load_chunk(ld_ch, ld);
       if (SCHED != 0 && kk == 0) __builtin_amdgcn_sched_barrier(0);
       read_step(kk + 4 < KCH ? kk + 4 : kk + 2, a0, b0);   // harmless re-read on the last trip
       __builtin_amdgcn_sched_barrier(0);
-      if (SCHED != 0 && kk + 4 >= KCH && more) store_chunk(buf ^ 1);
+      if (SCHED != 0 && kk + 4 >= KCH && do_st) store_chunk(buf ^ 1, stg);
       if (SCHED != 0 && kk + 4 >= KCH) __builtin_amdgcn_sched_barrier(0);
       mfma_step(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
+      WTRACE(12 + kk);
     }
-    if (SCHED == 0 && more) store_chunk(buf ^ 1);
+    WTRACE(3);
+    if (SCHED == 0 && do_st) store_chunk(buf ^ 1, stg);
+    WTRACE(4);
     __syncthreads();
+    WTRACE(5);
+  };
+
+  {
+    Stage st;
+    if (nchunks > 0) {
+      load_chunk(0, st);
+      store_chunk(0, st);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const bool more = ch + 1 < nchunks;
+      run_chunk(ch, ch & 1, st, ch + 1, more, st, more);
+    }
   }
 
+#ifdef PXO_TRACE_WGRAD
+  if (KIN == 256 && NOUT == 256 && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int base = g_wtrace_n;
+    for (int i = 0; i < s_tn && base + i < 2048; ++i) g_wtrace[base + i] = s_trace[i];
+    g_wtrace_n = base + s_tn;
+  }
+#endif
   float* out = slab + (int64_t)p * KIN * NOUT;
 #pragma unroll
   for (int r = 0; r < RB; ++r)
@@ -379,5 +425,17 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, (int64_t)mlp_bwd_partials(M), deg, grads);
   return check_launch("mlp_bwd_weights");
 }
+
+#ifdef PXO_TRACE_WGRAD
+extern "C" int pxo_debug_wtrace(unsigned long long* out, int cap, int reset) {
+  int n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wtrace_n), sizeof(int));
+  if (n > cap) n = cap;
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), sizeof(unsigned long long) * n);
+  if (reset) { int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace_n), &z, sizeof(int)); }
+  return n;
+}
+#endif
 
 }  // namespace pxo

@@ -430,6 +430,13 @@ def test_extraction_pipeline_end_to_end(tmp_path):
     want[:, -1].clamp_(min=0)
     # chunk boundaries reuse stream ids per `first`, so compare the first chunk only
     close("leaf data", tree.max_depth_data()[: 64 * 8], want[: 64 * 8], rtol=1e-5, atol=1e-6)
+    # the same extraction with the opt-in split-precision MLP forward (--mlp_precision bf16x3): same tree, same leaf data
+    # to the split-precision error (~1e-5 on values of order 1)
+    tree_x3 = extraction.main(common + ["--output", os.path.join(str(tmp_path), "tree_x3.npz"), "--init_grid_depth", "4",
+                                        "--masking_mode", "weight", "--samples_per_cell", "8", "--renderer_step_size", "1e-3",
+                                        "--eval", "false", "--mlp_precision", "bf16x3"])
+    assert torch.equal(tree_x3.child, tree.child)
+    close("leaf data, bf16x3 extraction", tree_x3.data.data, tree.data.data, rtol=1e-4, atol=2e-4)
     # the saved file loads and renders; early-stop and exact renders agree to the thresholds
     loaded = svox.N3Tree.load(out, map_location=dev)
     assert loaded.n_internal == tree.n_internal and torch.equal(loaded.child, tree.child)

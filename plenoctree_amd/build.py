@@ -93,6 +93,11 @@ if __name__ == "__main__":
         build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
     if "--variants2" in sys.argv:
         build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
+    if "--x3-variants" in sys.argv:
+        build(suffix="_x3g0", extra_flags=("-DPXO_X3_GEOM=0",))          # split-precision forward: 128-row tiles, 8 waves
+    if "--x3-ablations" in sys.argv:   # timing only, results wrong
+        for a in (1, 2, 3, 4):
+            build(suffix=f"_x3a{a}", extra_flags=(f"-DPXO_X3_ABL={a}",))
     if "--trace" in sys.argv:      # cycle-stamped wgrad kernel (timing experiment)
         build(suffix="_wtrace", extra_flags=("-DPXO_TRACE_WGRAD",))
     if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)

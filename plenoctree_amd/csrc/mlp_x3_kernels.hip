@@ -30,11 +30,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLDB = 264;                    // LDS row stride in bf16 (256 + 8: one b128 access of pad)
-constexpr int kX3Waves = kMlpThreads / 64;   // 8
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   hi = (__bf16)x;
   lo = (__bf16)(x - (float)hi);
+}
+// the same for a pair, packed: one v_cvt_pk_bf16_f32 per half, hi widened back with a shift / a mask
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  uint32_t hb;
+  __builtin_memcpy(&hb, &h, 4);
+  const float ha = __uint_as_float(hb << 16), hbf = __uint_as_float(hb & 0xffff0000u);
+  const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hbf)};
+  __builtin_memcpy(&lo, &l, 4);
+  hi = hb;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -105,12 +115,32 @@ int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipSt
 // ------------------------------------------------------------------------------------------
 struct X3Frag { bf16x8 hi, lo; };
 
-__device__ __forceinline__ X3Frag load_w(const f32x4* __restrict__ wp, int kg, int kg_stride) {
-  X3Frag f;
-  const f32x4 h = wp[(int64_t)kg * kg_stride], l = wp[(int64_t)kg * kg_stride + 64];
-  __builtin_memcpy(&f.hi, &h, 16);
-  __builtin_memcpy(&f.lo, &l, 16);
-  return f;
+// Geometry (build-time, PXO_X3_GEOM):
+//   0: 128-row tiles, one 8-wave workgroup per CU, every wave 128 rows x 32 features (the f32 kernel's geometry)
+//   1: 64-row tiles, TWO independent 4-wave workgroups per CU, every wave 64 rows x 64 features.  Per MFMA it reads half
+//      as many activation fragments from LDS and twice as many weight fragments from L2; the two workgroups drift
+//      apart, so one's posenc / epilogue / prologue phases run under the other's MFMAs.  With the three bf16 passes
+//      costing 3/16 of the f32 GEMM those phases are no longer small against the GEMM, which is why the geometry that
+//      lost for f32 (138 vs 150 TFLOP/s in the bare-loop probe) is measured here.
+#ifndef PXO_X3_GEOM
+#define PXO_X3_GEOM 1
+#endif
+#if PXO_X3_GEOM == 0
+constexpr int kXRows = 128, kXWaves = 8, kXCB = 1, kXWgPerCu = 1;
+#else
+constexpr int kXRows = 64, kXWaves = 4, kXCB = 2, kXWgPerCu = 2;
+#endif
+constexpr int kXThreads = kXWaves * 64;
+constexpr int kXRB = kXRows / 32;
+
+template <int CBN>
+__device__ __forceinline__ void load_w(const f32x4* __restrict__ wp, int64_t kg, int kg_stride, X3Frag (&w)[CBN]) {
+#pragma unroll
+  for (int c = 0; c < CBN; ++c) {
+    const f32x4 h = wp[kg * kg_stride + c * 128], l = wp[kg * kg_stride + c * 128 + 64];
+    __builtin_memcpy(&w[c].hi, &h, 16);
+    __builtin_memcpy(&w[c].lo, &l, 16);
+  }
 }
 
 template <int RBN>
@@ -122,48 +152,82 @@ __device__ __forceinline__ void load_x(const __bf16* __restrict__ xh, const __bf
   }
 }
 
-template <int RBN>
-__device__ __forceinline__ void mfma3(const X3Frag& w, const X3Frag (&x)[RBN], f32x16 (&acc)[RBN]) {
+template <int RBN, int CBN>
+__device__ __forceinline__ void mfma3(const X3Frag (&w)[CBN], const X3Frag (&x)[RBN], f32x16 (&acc)[RBN][CBN]) {
 #pragma unroll
-  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x[r].hi, acc[r], 0, 0, 0);
+  for (int r = 0; r < RBN; ++r)
 #pragma unroll
-  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x[r].lo, acc[r], 0, 0, 0);
+    for (int c = 0; c < CBN; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[c].hi, x[r].hi, acc[r][c], 0, 0, 0);
 #pragma unroll
-  for (int r = 0; r < RBN; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x[r].hi, acc[r], 0, 0, 0);
+  for (int r = 0; r < RBN; ++r)
+#pragma unroll
+    for (int c = 0; c < CBN; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[c].hi, x[r].lo, acc[r][c], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < RBN; ++r)
+#pragma unroll
+    for (int c = 0; c < CBN; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[c].lo, x[r].hi, acc[r][c], 0, 0, 0);
 }
 
-// weights (L2 latency) three k-groups ahead in four rotating register sets, activations (LDS) one ahead in two;
-// kgroups must be a multiple of 4.  xh / xl: this lane's row (lane & 31) and k offset 8 (lane >> 5) inside the planes.
+// Weights (L2 latency) three k-groups ahead in four rotating register sets `w` (owned by the caller), activations
+// (LDS) one ahead in two; kgroups must be a multiple of 4.  The weight fragments of a wave form ONE stream over the
+// k-groups of consecutive trunk layers (the images of layers l and l+1 are adjacent and have the same block shape), so
+// the loads "past the end" of a layer fetch the first three k-groups of the next one: `avail` = k-groups that may be
+// read starting at wp (>= kgroups), and a call with `preloaded` finds w[0..2] already holding its k-groups 0..2 --
+// the L2 latency of a layer's first fragments is then hidden under the previous layer's tail and its epilogue.
+// xh / xl: this lane's row (lane & 31) and k offset 8 (lane >> 5) inside the planes.
 #define PXO_X3_PIN() __builtin_amdgcn_sched_barrier(0)
-template <int RBN>
+template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_x3(const __bf16* __restrict__ xh, const __bf16* __restrict__ xl,
-                                        const f32x4* __restrict__ wp, int kgroups, int kg_stride, f32x16 (&acc)[RBN]) {
-  X3Frag w[4], x0[RBN], x1[RBN];
-  const int last = kgroups - 1;
+                                        const f32x4* __restrict__ wp, int kgroups, int avail, bool preloaded, int kg_stride,
+                                        X3Frag (&w)[4][CBN], f32x16 (&acc)[RBN][CBN]) {
+  X3Frag x0[RBN], x1[RBN];
+  const int last = avail - 1;
   auto cl = [&](int g) { return g < last ? g : last; };
+  if (!preloaded) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) w[i] = load_w(wp, cl(i), kg_stride);
+    for (int i = 0; i < 3; ++i) load_w<CBN>(wp, cl(i), kg_stride, w[i]);
+  }
+#ifndef PXO_X3_ABL
+#define PXO_X3_ABL 0            // timing-only ablations (results wrong): 1 posenc, 2 epilogue, 3 LDS operand reads, 4 weight loads
+                                // (measured, 2.10 ms base: 1.61 / - / 2.04 / 1.73 ms; the fast-sin experiment showed the posenc cost is not the sin)
+#endif
+#if PXO_X3_ABL == 3
+#define LOADX(g, x) asm volatile("" : "+v"(x[0].hi), "+v"(x[0].lo))
+#else
+#define LOADX(g, x) load_x<RBN>(xh, xl, g, x)
+#endif
+#if PXO_X3_ABL == 4
+#define LOADW(g, ww) asm volatile("" : "+v"(ww[0].hi), "+v"(ww[0].lo))
+#else
+#define LOADW(g, ww) load_w<CBN>(wp, cl(g), kg_stride, ww)
+#endif
   load_x<RBN>(xh, xl, 0, x0);
+#if PXO_X3_ABL == 3
+  load_x<RBN>(xh, xl, 1, x1);
+#endif
+#if PXO_X3_ABL == 4
+  load_w<CBN>(wp, 0, kg_stride, w[3]);
+#endif
   for (int g = 0; g < kgroups; g += 4) {
-    load_x<RBN>(xh, xl, g + 1, x1);
-    w[3] = load_w(wp, cl(g + 3), kg_stride);
+    LOADX(g + 1, x1);
+    LOADW(g + 3, w[3]);
     PXO_X3_PIN();
-    mfma3<RBN>(w[0], x0, acc);
+    mfma3<RBN, CBN>(w[0], x0, acc);
     PXO_X3_PIN();
-    load_x<RBN>(xh, xl, g + 2, x0);
-    w[0] = load_w(wp, cl(g + 4), kg_stride);
+    LOADX(g + 2, x0);
+    LOADW(g + 4, w[0]);
     PXO_X3_PIN();
-    mfma3<RBN>(w[1], x1, acc);
+    mfma3<RBN, CBN>(w[1], x1, acc);
     PXO_X3_PIN();
-    load_x<RBN>(xh, xl, g + 3, x1);
-    w[1] = load_w(wp, cl(g + 5), kg_stride);
+    LOADX(g + 3, x1);
+    LOADW(g + 5, w[1]);
     PXO_X3_PIN();
-    mfma3<RBN>(w[2], x0, acc);
+    mfma3<RBN, CBN>(w[2], x0, acc);
     PXO_X3_PIN();
-    load_x<RBN>(xh, xl, cl(g + 4), x0);
-    w[2] = load_w(wp, cl(g + 6), kg_stride);
+    LOADX((g + 4 < kgroups ? g + 4 : kgroups - 1), x0);
+    LOADW(g + 6, w[2]);
     PXO_X3_PIN();
-    mfma3<RBN>(w[3], x1, acc);
+    mfma3<RBN, CBN>(w[3], x1, acc);
     PXO_X3_PIN();
   }
 }
@@ -186,11 +250,15 @@ __device__ __forceinline__ float x3_enc_value(float p0, float p1, float p2, int 
   return sinf(xb);
 }
 
-// posenc of the tile's 128 points, split, into planes[:, 0:64]
+// posenc of the tile's points, split, into planes[:, 0:64]
 __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* __restrict__ pl, const float* __restrict__ pts,
                                                const X3Grid& grid, int64_t row0, int64_t M, int tid) {
-  const int row = tid % kTM, part = tid / kTM;          // 4 parts x 16 columns
+  static_assert(kXThreads / kXRows == 4, "4 parts x 16 columns");
+  const int row = tid % kXRows, part = tid / kXRows;
   const int64_t grow = row0 + row;
+#if PXO_X3_ABL == 1
+  if (grow >= 0) return;
+#endif
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
   if (grow < M) {
     if (grid.enabled) {
@@ -207,15 +275,13 @@ __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* 
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    bf16x8 vh, vl;
+    uint32_t vh[4], vl[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __bf16 a, b;
-      split_bf16(x3_enc_value(p0, p1, p2, part * 16 + h * 8 + i), a, b);
-      vh[i] = a; vl[i] = b;
-    }
-    *reinterpret_cast<bf16x8*>(ph + row * kLDB + part * 16 + h * 8) = vh;
-    *reinterpret_cast<bf16x8*>(pl + row * kLDB + part * 16 + h * 8) = vl;
+    for (int i = 0; i < 4; ++i)
+      split_bf16_pair(x3_enc_value(p0, p1, p2, part * 16 + h * 8 + 2 * i), x3_enc_value(p0, p1, p2, part * 16 + h * 8 + 2 * i + 1),
+                      vh[i], vl[i]);
+    *reinterpret_cast<uint4*>(ph + row * kLDB + part * 16 + h * 8) = make_uint4(vh[0], vh[1], vh[2], vh[3]);
+    *reinterpret_cast<uint4*>(pl + row * kLDB + part * 16 + h * 8) = make_uint4(vl[0], vl[1], vl[2], vl[3]);
   }
 }
 
@@ -223,12 +289,12 @@ __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* 
 // forward
 // ------------------------------------------------------------------------------------------
 template <int NHB, bool RGB>
-__global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_x3_kernel(
+__global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3_kernel(
     const float* __restrict__ pk, const float* __restrict__ pts, X3Grid grid, int64_t M, int deg,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma) {
-  __shared__ __attribute__((aligned(16))) __bf16 plane_h[kTM * kLDB];
-  __shared__ __attribute__((aligned(16))) __bf16 plane_l[kTM * kLDB];
-  constexpr int kRB = kTM / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 plane_h[kXRows * kLDB];
+  __shared__ __attribute__((aligned(16))) __bf16 plane_l[kXRows * kLDB];
+  __shared__ __attribute__((aligned(16))) float s_bias[kDepth * kW];      // trunk biases, staged once per workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = rgb_channels(deg);
@@ -236,69 +302,82 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_x3_kernel(
   // this lane's operand position: sample row (lane & 31) of a row block, k offset 8 (lane >> 5) of a k-group
   const __bf16* xh = plane_h + (lane & 31) * kLDB + (lane >> 5) * 8;
   const __bf16* xl = plane_l + (lane & 31) * kLDB + (lane >> 5) * 8;
-  const int64_t ntiles = num_tiles(M);
+  const int64_t ntiles = (M + kXRows - 1) / kXRows;
+  for (int i = tid; i < kDepth * kW; i += kXThreads) s_bias[i] = bias[i];
+  // this wave's weight stream over the trunk: blocks (kg, cb = wave*kXCB + c, part), 2 x 64 f32x4 per (kg, cb);
+  // 4 + 16*4 + 20 + 16*2 = 120 k-groups from layer 0 to layer 7
+  const f32x4* wp0 = reinterpret_cast<const f32x4*>(pk) + (int64_t)(wave * kXCB) * 128 + lane;
+  constexpr int kTrunkKg = 120;
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * kTM;
+    const int64_t row0 = tile * kXRows;
     __syncthreads();   // previous tile's head GEMM has consumed the planes
     posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
     __syncthreads();
 
-    f32x16 acc[kRB];
+    f32x16 acc[kXRB][kXCB];
+    X3Frag w[4][kXCB];
+    int kg0 = 0;          // position of the running layer in the wave's weight stream
     for (int l = 0; l < kDepth; ++l) {
 #pragma unroll
-      for (int r = 0; r < kRB; ++r)
+      for (int r = 0; r < kXRB; ++r)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
-      // fragments of this wave's 32 output features: (kg, cb = wave, part) blocks, 2 x 64 f32x4 per (kg, cb)
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (int64_t)wave * 128 + lane;
-      gemm_x3<kRB>(xh, xl, wp, l == 0 ? 4 : 16, 8 * 128, acc);
+        for (int c = 0; c < kXCB; ++c)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+      const int nkg = l == 0 ? 4 : 16;
+      gemm_x3<kXRB, kXCB>(xh, xl, wp0 + (int64_t)kg0 * (8 * 128), nkg, kTrunkKg - kg0, l > 0, 8 * 128, w, acc);
+      kg0 += nkg;
       if (l == 5) {
         // skip connection (model_utils.py:70-71): the 64 encoded columns are a second K segment, recomputed in place
         __syncthreads();
         posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
         __syncthreads();
-        gemm_x3<kRB>(xh, xl, wp + (int64_t)16 * 8 * 128, 4, 8 * 128, acc);
+        gemm_x3<kXRB, kXCB>(xh, xl, wp0 + (int64_t)kg0 * (8 * 128), 4, kTrunkKg - kg0, true, 8 * 128, w, acc);
+        kg0 += 4;
       }
       __syncthreads();  // every wave has consumed the input planes
       // epilogue: lane holds features n0 .. n0+3 of sample m per register quad
+#if PXO_X3_ABL == 2
+      asm volatile("" :: "v"(acc[0][0]), "v"(acc[kXRB - 1][kXCB - 1]));
+#else
 #pragma unroll
-      for (int r = 0; r < kRB; ++r) {
+      for (int r = 0; r < kXRB; ++r) {
         const int m = r * 32 + (lane & 31);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + l * kW + n0);
-          bf16x4 vh, vl;
+        for (int c = 0; c < kXCB; ++c)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            __bf16 a, b;
-            split_bf16(fmaxf(acc[r][4 * q + t] + b4[t], 0.f), a, b);
-            vh[t] = a; vl[t] = b;
+          for (int q = 0; q < 4; ++q) {
+            const int n0 = (wave * kXCB + c) * 32 + 8 * q + 4 * (lane >> 5);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + l * kW + n0);
+            uint32_t h01, l01, h23, l23;
+            split_bf16_pair(fmaxf(acc[r][c][4 * q] + b4[0], 0.f), fmaxf(acc[r][c][4 * q + 1] + b4[1], 0.f), h01, l01);
+            split_bf16_pair(fmaxf(acc[r][c][4 * q + 2] + b4[2], 0.f), fmaxf(acc[r][c][4 * q + 3] + b4[3], 0.f), h23, l23);
+            *reinterpret_cast<uint2*>(plane_h + m * kLDB + n0) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(plane_l + m * kLDB + n0) = make_uint2(l01, l23);
           }
-          *reinterpret_cast<bf16x4*>(plane_h + m * kLDB + n0) = vh;
-          *reinterpret_cast<bf16x4*>(plane_l + m * kLDB + n0) = vl;
-        }
       }
+#endif
       __syncthreads();
     }
 
-    // heads (model_utils.py:72-74, :91-93): wave w owns row block w % 4 and head blocks w / 4, w / 4 + 2, ...;
+    // heads (model_utils.py:72-74, :91-93): wave w owns row block w % kXRB and head blocks w / kXRB, + CSTEP, ...;
     // sigma only (RGB = false): the block that holds column C
     {
-      constexpr int CSTEP = kX3Waves / kRB;               // 2 waves per row block
+      constexpr int CSTEP = kXWaves / kXRB;               // waves per row block (2)
       constexpr int HMAX = RGB ? (NHB + CSTEP - 1) / CSTEP : 1;
-      const int rb = wave % kRB, cb0 = wave / kRB;
+      const int rb = wave % kXRB, cb0 = wave / kXRB;
       const float* hb = bias + 8 * kW;
 #pragma unroll 1
       for (int i = 0; i < HMAX; ++i) {
         const int cb = RGB ? cb0 + i * CSTEP : (cb0 == 0 ? NHB - 1 : NHB);
         if (cb >= NHB) continue;                           // wave-uniform
-        f32x16 hacc[1];
+        f32x16 hacc[1][1];
+        X3Frag hw[4][1];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) hacc[0][j] = 0.f;
+        for (int j = 0; j < 16; ++j) hacc[0][0][j] = 0.f;
         const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + (int64_t)cb * 128 + lane;
-        gemm_x3<1>(xh + rb * 32 * kLDB, xl + rb * 32 * kLDB, wp, 16, NHB * 128, hacc);
+        gemm_x3<1, 1>(xh + rb * 32 * kLDB, xl + rb * 32 * kLDB, wp, 16, 16, false, NHB * 128, hw, hacc);
         const int64_t grow = row0 + rb * 32 + (lane & 31);
         if (grow < M) {
 #pragma unroll
@@ -306,7 +385,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void mlp_fwd_x3_kernel(
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int col = cb * 32 + 8 * q + 4 * (lane >> 5) + t;
-              const float v = hacc[0][4 * q + t] + hb[col];
+              const float v = hacc[0][0][4 * q + t] + hb[col];
               if (col < C) { if (RGB) raw_rgb[grow * C + col] = v; }
               else if (col == C) raw_sigma[grow] = v;
             }
@@ -320,8 +399,8 @@ template <int NHB>
 static int launch_x3_nhb(const PxoCfg* cfg, const float* pk, const float* pts, const X3Grid& grid, int64_t M,
                          float* raw_rgb, float* raw_sigma, hipStream_t s) {
   KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
-  const int64_t tiles = num_tiles(M), cap = num_cus();
-  dim3 grid_dim((unsigned)(tiles < cap ? tiles : cap)), block(kMlpThreads);
+  const int64_t tiles = (M + kXRows - 1) / kXRows, cap = (int64_t)kXWgPerCu * num_cus();
+  dim3 grid_dim((unsigned)(tiles < cap ? tiles : cap)), block(kXThreads);
   if (raw_rgb)
     hipLaunchKernelGGL((mlp_fwd_x3_kernel<NHB, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, raw_rgb, raw_sigma);
   else

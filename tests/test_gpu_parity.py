@@ -550,6 +550,38 @@ def test_full_size_properties():
     assert torch.isfinite(out[1][0]).all()
 
 
+def _check_gen_mesh(common, train_dir):
+    """nerf_sh/gen_mesh.py on the restored checkpoint: the sigma grid comes from the HIP evaluator, the OBJ holds the
+    isosurface of exactly that grid, and the surface really sits on the level set (sigma re-evaluated at the vertices)."""
+    from plenoctree_amd.nerf_sh import gen_mesh
+    from plenoctree_amd.nerf_sh.nerf import models, utils
+    dev = torch.device("cuda:0")
+    args = gen_mesh.define_flags().parse_args(common)
+    utils.update_flags(args)
+    model, state = models.get_model_state(args, dev, restore=True)
+    fn = lambda p: model.eval_points_raw(state, p, want_rgb=False)[1]
+    reso, c1, c2 = [40, 36, 32], [-1.5] * 3, [1.5] * 3
+    sig = gen_mesh.sigma_grid(fn, c1, c2, reso, 7001, dev)            # ragged chunks
+    assert sig.shape == tuple(reso)
+    # against the evaluator on the explicit meshgrid point list (the reference's construction, gen_mesh.py:105-111)
+    grid = np.vstack(np.meshgrid(*(np.linspace(lo, hi, sz, dtype=np.float32) for lo, hi, sz in zip(c1, c2, reso)),
+                                 indexing="ij")).reshape(3, -1).T
+    ref = fn(torch.from_numpy(np.ascontiguousarray(grid)).to(dev)).reshape(*reso)
+    assert torch.equal(sig, ref)
+    iso = float(sig.median())
+    verts, faces = gen_mesh.main(common + ["--reso", "40 36 32", "--c1", "-1.5", "--c2", "1.5", "--iso", repr(iso),
+                                           "--point_chunk", "7001"])
+    assert len(verts) > 100 and len(faces) > 100 and faces.min() >= 0 and faces.max() < len(verts)
+    lines = open(os.path.join(train_dir, "mesh.obj")).read().splitlines()
+    assert sum(l.startswith("v ") for l in lines) == len(verts) and sum(l.startswith("f ") for l in lines) == len(faces)
+    # undo the reference's (c2-c1)/reso scaling (:127) to get back to sample space, then re-evaluate sigma there
+    idx = (verts - np.array(c1)) * np.array(reso) / (np.array(c2) - np.array(c1))
+    pos = np.array(c1) + idx * (np.array(c2) - np.array(c1)) / (np.array(reso) - 1)
+    s_at = fn(torch.from_numpy(pos.astype(np.float32)).to(dev)).reshape(-1).cpu().numpy()
+    spread = float(sig.std())
+    assert np.median(np.abs(s_at - iso)) < 0.1 * spread, (np.median(np.abs(s_at - iso)), spread)
+
+
 def test_cli_train_eval_extraction(tmp_path):
     """The drop-in entry points end to end on the synthetic scene: loss falls, checkpoint
     round-trips, eval renders with deterministic sampling, extraction evaluates the sigma grid."""
@@ -582,6 +614,7 @@ def test_cli_train_eval_extraction(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "video", "e300", "frames", "0001.png"))
     assert os.path.exists(os.path.join(str(tmp_path), "video", "e300", "video.gif"))
     assert np.loadtxt(os.path.join(str(tmp_path), "poses.txt")).shape == (8, 4)
+    _check_gen_mesh(common, str(tmp_path))
     # the extraction driver restores the same checkpoint and evaluates its sigma grid (32^3 here); the complete
     # extraction -> optimisation -> evaluation chain is exercised in tests/test_gpu_octree.py
     from plenoctree_amd.nerf_sh.nerf import models, utils

@@ -98,6 +98,9 @@ if __name__ == "__main__":
     if "--x3-ablations" in sys.argv:   # timing only, results wrong
         for a in (1, 2, 3, 4):
             build(suffix=f"_x3a{a}", extra_flags=(f"-DPXO_X3_ABL={a}",))
+    if "--oct-ablations" in sys.argv:  # timing only, results wrong: octree backward without / with plain-store scatter
+        for a in (1, 2, 3):
+            build(suffix=f"_octa{a}", extra_flags=(f"-DPXO_OCT_ABL={a}",))
     if "--trace" in sys.argv:      # cycle-stamped wgrad kernel (timing experiment)
         build(suffix="_wtrace", extra_flags=("-DPXO_TRACE_WGRAD",))
     if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)

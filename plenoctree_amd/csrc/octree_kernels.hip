@@ -423,6 +423,9 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 constexpr int kRenderThreads = 256;
 
+#ifndef PXO_OCT_ABL
+#define PXO_OCT_ABL 0
+#endif
 // lanes per ray: ROW in {4, 8, 16}; the wave carries 64/ROW rays as a WTX x WTY pixel patch
 template <int ROW> struct RowGeom {
   static constexpr int kRaysPerWave = 64 / ROW;
@@ -589,6 +592,9 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     first_pass = 1;
   }
 
+#if PXO_OCT_ABL
+  float abl_acc = 0.0f;
+#endif
   // pass 0 composites; in MODE 1 pass 1 re-marches and scatters the gradient
   for (int pass = first_pass; pass <= MODE; ++pass) {
     Marcher mk;
@@ -654,12 +660,22 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
           for (int j = 0; j < kMaxLoads; ++j) {
             if (j < nload) {
               const int idx = l + kRow * j;
+#if PXO_OCT_ABL == 1 || PXO_OCT_ABL == 2     // timing experiments (results wrong): no coefficient atomics
+              if (idx < D - 1) abl_acc += (b0[j] * d0 + b1[j] * d1) + b2[j] * d2;
+#elif PXO_OCT_ABL == 3                        // plain (racy) stores instead of atomics
+              if (idx < D - 1) gv[idx] = (b0[j] * d0 + b1[j] * d1) + b2[j] * d2;
+#else
               if (idx < D - 1) unsafeAtomicAdd(gv + idx, (b0[j] * d0 + b1[j] * d1) + b2[j] * d2);
+#endif
             }
           }
           light = light * att;
           accum -= weight * total;
+#if PXO_OCT_ABL == 2
+          abl_acc += dtw * (total * light - accum);
+#else
           if (l == 0) unsafeAtomicAdd(gv + D - 1, dtw * (total * light - accum));
+#endif
         }
       }
       const float tn = t + delta_t;
@@ -677,6 +693,9 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
       }
     }
   }
+#if PXO_OCT_ABL
+  if (MODE == 1 && abl_acc == 123.456f) grad_data[0] = abl_acc;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

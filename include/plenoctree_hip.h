@@ -9,6 +9,9 @@
  * call is asynchronous on the hipStream_t given as `void* stream`.
  *
  * Return value: 0 = ok, negative = error (message via pxo_last_error()).
+ * Empty inputs (a row / ray / point count of 0) return 0 without touching any pointer, so zero-size
+ * tensors (NULL data pointers) are valid arguments; pxo_train_fwd_bwd alone requires B >= 1 (a mean over no
+ * rays has no value).
  *
  * Layouts (all float32, row-major):
  *   rays      origins/directions/viewdirs [B,3]         (nerf_sh/nerf/utils.py:53 Rays)

@@ -248,12 +248,14 @@ int pxo_pack_weights(const PxoCfg* cfg, const float* mlp_params, float* packed_f
 int pxo_sample_along_rays(const float* origins, const float* directions, int64_t B, int S, float near_, float far_,
                           int lindisp, const float* t_rand, float* z_vals, float* pts, void* stream) {
   PXO_REQUIRE(B >= 0 && S >= 1, "pxo_sample_along_rays: bad sizes B=%lld S=%d", (long long)B, S);
+  if (B == 0) return PXO_OK;                   // empty input: nothing to check, nothing to launch
   PXO_REQUIRE(origins && directions && z_vals && pts, "pxo_sample_along_rays: NULL pointer");
   return launch_sample_along_rays(origins, directions, B, S, near_, far_, lindisp, t_rand, z_vals, pts,
                                   (hipStream_t)stream);
 }
 
 int pxo_posenc(const float* x, int64_t N, float* enc, void* stream) {
+  if (N == 0) return PXO_OK;
   PXO_REQUIRE(N >= 0 && x && enc, "pxo_posenc: bad arguments");
   return launch_posenc(x, N, enc, (hipStream_t)stream);
 }
@@ -303,6 +305,7 @@ int pxo_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float
                             const float* directions, const float* viewdirs, int64_t B, int S, float* comp_rgb,
                             float* disp, float* acc, float* weights, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (B == 0) return PXO_OK;
   PXO_REQUIRE(B >= 0 && raw_rgb && raw_sigma && z_vals && directions && viewdirs && comp_rgb && disp && acc && weights,
               "pxo_shade_composite_fwd: bad arguments");
   return launch_shade_composite_fwd(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, B, S, comp_rgb, disp, acc,
@@ -313,6 +316,7 @@ int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float
                             const float* directions, const float* viewdirs, const float* d_comp_rgb, int64_t B, int S,
                             float* d_raw_rgb, float* d_raw_sigma, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (B == 0) return PXO_OK;
   PXO_REQUIRE(B >= 0 && raw_rgb && raw_sigma && z_vals && directions && viewdirs && d_comp_rgb && d_raw_rgb &&
                   d_raw_sigma,
               "pxo_shade_composite_bwd: bad arguments");
@@ -322,22 +326,26 @@ int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float
 
 int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* origins, const float* directions,
                    int64_t B, int Nc, int Nf, const float* u, float* z_out, float* pts, void* stream) {
+  if (B == 0) return PXO_OK;
   PXO_REQUIRE(B >= 0 && z_coarse && w_coarse && origins && directions && z_out && pts, "pxo_sample_pdf: bad arguments");
   return launch_sample_pdf(z_coarse, w_coarse, origins, directions, B, Nc, Nf, u, z_out, pts, (hipStream_t)stream);
 }
 
 int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, void* stream) {
+  if (n == 0) return PXO_OK;
   PXO_REQUIRE(n >= 0 && out, "pxo_uniform: bad arguments");
   return launch_uniform(seed, stream_id, n, lo, hi, out, (hipStream_t)stream);
 }
 
 int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, void* stream) {
+  if (count == 0) return PXO_OK;
   PXO_REQUIRE(count >= 0 && n >= 1 && out, "pxo_randint: bad arguments");
   return launch_randint(seed, stream_id, count, n, out, (hipStream_t)stream);
 }
 
 int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pixel_ids, int64_t B,
                       float* origins, float* directions, float* viewdirs, void* stream) {
+  if (B == 0) return PXO_OK;
   PXO_REQUIRE(B >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && origins && directions && viewdirs,
               "pxo_generate_rays: bad arguments");
   return launch_generate_rays(c2w, 1, W, H, focal, pixel_ids, B, origins, directions, viewdirs, (hipStream_t)stream);
@@ -345,6 +353,7 @@ int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t
 
 int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids, int64_t B,
                             float* origins, float* directions, float* viewdirs, void* stream) {
+  if (B == 0) return PXO_OK;
   PXO_REQUIRE(B >= 0 && n_cams >= 1 && W >= 1 && H >= 1 && focal > 0.f && c2w && ray_ids && origins && directions &&
                   viewdirs,
               "pxo_generate_rays_multi: bad arguments");
@@ -355,12 +364,14 @@ int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float fo
 int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S,
                           float* out, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (n_cells == 0) return PXO_OK;
   PXO_REQUIRE(n_cells >= 0 && S >= 1 && raw_rgb && raw_sigma && out, "pxo_mean_over_samples: bad arguments");
   return launch_mean_samples(raw_rgb, raw_sigma, n_cells, S, rgb_channels(cfg->sh_deg), out, (hipStream_t)stream);
 }
 
 int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t n, float lr, int64_t step,
                   float grad_scale, void* stream) {
+  if (n == 0) return PXO_OK;
   PXO_REQUIRE(n >= 0 && params && m && v && grads && step >= 0, "pxo_adam_step: bad arguments");
   return launch_adam(params, m, v, grads, n, lr, step, grad_scale, (hipStream_t)stream);
 }
@@ -379,6 +390,7 @@ int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* pac
                    const float* u, uint64_t seed, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f,
                    float* disp_f, float* acc_f, void* ws, size_t ws_bytes, void* stream) {
   PXO_TRY(validate_cfg(cfg));
+  if (B == 0) return PXO_OK;                   // an empty batch has no buffers to check
   PXO_REQUIRE(B >= 0 && packed_fwd0 && origins && directions && viewdirs && rgb_c && disp_c && acc_c && ws,
               "pxo_render_fwd: bad arguments");
   if (cfg->num_fine_samples > 0)
@@ -389,7 +401,6 @@ int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* pac
     set_error("pxo_render_fwd: workspace %zu < %zu", ws_bytes, t.total);
     return PXO_ERR_WORKSPACE;
   }
-  if (B == 0) return PXO_OK;
   return run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
                      nullptr, seed, false, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, (hipStream_t)stream);
 }
@@ -502,8 +513,9 @@ int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* poi
 int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1, const float offset[3],
                    const float scale[3], float* sigma_out, void* stream) {
   PXO_TRY(validate_cfg(cfg));
-  PXO_REQUIRE(packed_fwd && offset && scale && sigma_out, "pxo_grid_sigma: NULL pointer");
   PXO_REQUIRE(reso >= 1 && x0 >= 0 && x1 >= x0 && x1 <= reso, "pxo_grid_sigma: bad slab [%d,%d) of %d", x0, x1, reso);
+  if (x1 == x0) return PXO_OK;
+  PXO_REQUIRE(packed_fwd && offset && scale && sigma_out, "pxo_grid_sigma: NULL pointer");
   return launch_mlp_fwd_grid(cfg, packed_fwd, reso, x0, x1, offset, scale, sigma_out, (hipStream_t)stream);
 }
 

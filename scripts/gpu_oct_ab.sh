@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 R=$PWD
-[ -n "${PYTEST_ARGS:-}" ] && { timeout 600 python -m pytest ${PYTEST_ARGS} -q --tb=short -p no:cacheprovider > gpurun_out/pytest_ab.log 2>&1; echo "pytest exit $?"; tail -15 gpurun_out/pytest_ab.log; }
+[ -n "${PYTEST_ARGS:-}" ] && { timeout 600 python -m pytest ${PYTEST_ARGS} ${PYTEST_K:+-k "$PYTEST_K"} -q --tb=short -p no:cacheprovider > gpurun_out/pytest_ab.log 2>&1; echo "pytest exit $?"; tail -15 gpurun_out/pytest_ab.log; }
 for sfx in ${LIBS:-main}; do
   [ "$sfx" = "main" ] && lib=$R/plenoctree_amd/libplenoctree_hip.so || lib=$R/plenoctree_amd/libplenoctree_hip$sfx.so
   [ -f "$lib" ] || { echo "missing $lib"; continue; }

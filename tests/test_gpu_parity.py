@@ -809,3 +809,47 @@ def test_error_paths_on_device():
                           torch.zeros(6, device=dev), torch.empty(1024, dtype=torch.uint8, device=dev))
     with pytest.raises(_lib.PxoError):
         ops.posenc(torch.zeros(4, 3))          # host tensor
+
+
+def test_empty_inputs_are_accepted():
+    """Zero rows / rays / points: every entry point returns without touching its (NULL) buffers; shapes survive."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)
+    flat = make_params(cfg).to(dev)
+    packed = [ops.pack_weights(pcfg, split_mlp(flat, cfg, i), need_bwd=False) for i in range(2)]
+    e3 = torch.zeros(0, 3, device=dev)
+    rgb, sig = ops.eval_points(pcfg, packed[1][0], e3)
+    assert rgb.shape == (0, 48) and sig.shape == (0, 1)
+    out = ops.render_fwd(pcfg, packed[0][0], packed[1][0], e3, e3, e3)
+    assert len(out) == 2 and out[1][0].shape == (0, 3) and out[1][1].shape == (0,)
+    assert ops.posenc(e3).shape[0] == 0
+    assert ops.uniform(1, 0, 0).numel() == 0 and ops.randint(1, 0, 0, 10).numel() == 0
+    o, d, v = ops.generate_rays(torch.eye(4, device=dev)[:3], 8, 8, 10.0, pixel_ids=torch.zeros(0, dtype=torch.int64, device=dev))
+    assert o.shape == (0, 3) and d.shape == (0, 3) and v.shape == (0, 3)
+    assert ops.grid_sigma(pcfg, packed[1][0], 16, 5, 5, [0.0] * 3, [1.0] * 3).numel() == 0
+    p = torch.zeros(0, device=dev)
+    ops.adam_step(p, p.clone(), p.clone(), p.clone(), 1e-3, 1)
+    torch.cuda.synchronize()
+    from plenoctree_amd import _lib
+    with pytest.raises(_lib.PxoError):                      # the train step needs at least one ray
+        ops.train_fwd_bwd(pcfg, flat, [ops.pack_weights(pcfg, split_mlp(flat, cfg, i)) for i in range(2)], e3, e3, e3, e3,
+                          torch.zeros_like(flat), torch.zeros(6, device=dev), torch.empty(1 << 20, dtype=torch.uint8, device=dev))
+
+
+def test_eval_points_past_2g_output_elements():
+    """64-bit addressing: 46 M points x 48 coefficients = 2.2 G output floats (8.8 GB).  The evaluator is row-independent
+    and bit-reproducible, so rows sampled from the big launch must equal the same points evaluated as a small batch."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)
+    flat = make_params(cfg)
+    pf, _ = ops.pack_weights(pcfg, split_mlp(flat, cfg, 1).to(dev), need_bwd=False)
+    N = 46_000_003
+    pts = ops.uniform(11, 0, N * 3, -1.5, 1.5).reshape(N, 3)
+    rgb, sig = ops.eval_points(pcfg, pf, pts)
+    assert rgb.numel() > 2 ** 31
+    pick = torch.cat([torch.arange(0, 300, device=dev), torch.arange(N - 300, N, device=dev),
+                      torch.arange(44_739_243 - 150, 44_739_243 + 150, device=dev),        # around element 2^31
+                      ops.randint(12, 0, 2000, N)])
+    rgb_s, sig_s = ops.eval_points(pcfg, pf, pts[pick].contiguous())
+    assert torch.equal(rgb[pick], rgb_s) and torch.equal(sig[pick], sig_s)
+    assert bool(torch.isfinite(sig).all())

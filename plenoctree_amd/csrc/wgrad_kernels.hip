@@ -7,11 +7,16 @@
 // are 32 consecutive floats of one LDS row -> conflict-free ds_read_b32), keeps the whole
 // KIN x NOUT product in accumulators and writes one slab; a second kernel adds the slabs in a
 // fixed order (deterministic, no float atomics).
+#include <cstdlib>
+
 #include "pxo_common.h"
 
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
+#ifndef PXO_WGRAD_BATCH
+#define PXO_WGRAD_BATCH 1         // 1: Dense_1..7's products in one launch (0: one launch per layer, for A/B)
+#endif
 #ifndef PXO_WGRAD_SMALL
 #define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
 #endif
@@ -40,7 +45,8 @@ __device__ int g_wtrace_n;
 template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false, int SCHED = 0>
 __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
-    int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr) {
+    int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr,
+    int n_layers = 1, int64_t layer_stride = 0) {
   static_assert(WR * WC * 64 == NT, "wave grid");
   static_assert(!DUAL || (NOUT == 2 * kW && NSPLIT == 1 && !HEAD), "dual source: two 256-wide arrays, no split");
   constexpr int NTILE = NOUT / NSPLIT;
@@ -60,10 +66,20 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
+  // n_layers > 1: the grid is n_layers equal groups of blocks; group g computes the product of the arrays
+  // X + g layer_stride, dZ + g layer_stride into its own P slabs (the 256x256 products of Dense_1..7 in ONE launch)
+  int bid = blockIdx.x;
+  if (n_layers > 1) {
+    const int per = gridDim.x / n_layers, g = bid / per;
+    bid -= g * per;
+    X += (int64_t)g * layer_stride;
+    dZ += (int64_t)g * layer_stride;
+    slab += (int64_t)g * P * KIN * NOUT;
+  }
   int p, half;
-  if (NSPLIT == 1) { p = blockIdx.x; half = 0; }
+  if (NSPLIT == 1) { p = bid; half = 0; }
   else {
-    const int grp = blockIdx.x / (8 * NSPLIT), r = blockIdx.x % (8 * NSPLIT);
+    const int grp = bid / (8 * NSPLIT), r = bid % (8 * NSPLIT);
     p = grp * 8 + (r & 7);
     half = r >> 3;
   }
@@ -247,7 +263,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
                                                           int rows_valid, int col0, int ncols,
                                                           float* __restrict__ dst, int dst_ld,
-                                                          float* __restrict__ dst2, int col0_2) {
+                                                          float* __restrict__ dst2, int col0_2,
+                                                          int layer0 = -1, int deg = 0) {
+  if (layer0 >= 0) {               // batched: blockIdx.y = layer group; dst is the gradient arena of the MLP
+    slab += (int64_t)blockIdx.y * P * kin * nout;
+    dst += leaf_kernel_off(layer0 + (int)blockIdx.y, deg);
+  }
   __shared__ f32x4 red[4][64];
   const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e4 = (int64_t)blockIdx.x * 64 + v;            // float4 index inside one slab
@@ -315,7 +336,11 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
   // 2 num_cus() (the skinny products run two workgroups per CU); the size does not depend on M (two passes of
   // different M share one workspace)
   (void)cfg; (void)M;
+#if PXO_WGRAD_BATCH
+  return (size_t)(kDepth - 1) * num_cus() * kW * kW * sizeof(float);     // Dense_1..7 in one launch: a slab set per layer
+#else
   return (size_t)num_cus() * kW * kW * sizeof(float);
+#endif
 }
 
 template <int NHB>
@@ -345,7 +370,11 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
 #if PXO_WGRAD_SMALL == 0
   split_rows(M, num_cus(), &rpw2, &P2);
 #else
-  split_rows(M, 2 * (int64_t)num_cus(), &rpw2, &P2);
+  {
+    static const int ranges2_override = getenv("PXO_WGRAD_RANGES2") ? atoi(getenv("PXO_WGRAD_RANGES2")) : 0;   // A/B hook
+    split_rows(M, ranges2_override > 0 && ranges2_override <= 2 * num_cus() ? ranges2_override : 2 * (int64_t)num_cus(),
+               &rpw2, &P2);
+  }
 #endif
   if (ws_bytes < (size_t)P * kW * kW * sizeof(float) || ws_bytes < (size_t)P2 * kEncPad * 2 * kW * sizeof(float)) {
     set_error("wgrad workspace too small: %zu < %zu", ws_bytes, (size_t)P * kW * kW * sizeof(float));
@@ -377,8 +406,40 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW,
           grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
 #endif
+#if PXO_WGRAD_BATCH
+  // Dense_1..7: h_{l-1}^T dz_l (for l = 5 these are the first 256 input rows) in ONE launch: acts and dz are [8][M,256]
+  // stacks, so layer l is "group l-1" of the kernel with layer_stride = M*256.  The row ranges are 7x longer than with a
+  // launch per layer (same number of workgroups in flight), i.e. 1/7 of the slab traffic and of the ramp-up/tail, and
+  // 2 launches instead of 14 - what small batches (rays/GPU of the strong-scaling shape) pay most for.
+  {
+    constexpr int NL = kDepth - 1;
+    int64_t rpwb; int Pb;
+    // Row ranges per layer: the grid is NL x ranges x 2 column halves on 2 num_cus() slots, all of equal work, so whole
+    // "waves" of workgroups are what to aim for: num_cus() ranges = NL waves; 4 num_cus() / NL = 4 waves.  Measured
+    // (rays/s at 4096 / 1024 / 512 rays per step, 256 CUs): 256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k /
+    // 144.3 k / 127.9 k (one launch per layer: 159.7 k / 139.9 k / 120.3 k) - long ranges lose on big passes (the two
+    // column halves drift apart and the shared operand stops hitting L2), short ones pay 64 MB of slab traffic per layer.
+    static const int ranges_override = getenv("PXO_WGRAD_RANGES") ? atoi(getenv("PXO_WGRAD_RANGES")) : 0;   // A/B hook
+    int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
+    if (ranges_override > 0 && ranges_override <= num_cus()) ranges = ranges_override;
+    split_rows(M, ranges, &rpwb, &Pb);
+    if (ws_bytes < (size_t)NL * Pb * kW * kW * sizeof(float)) {
+      set_error("wgrad workspace too small: %zu < %zu", ws_bytes, (size_t)NL * Pb * kW * kW * sizeof(float));
+      return PXO_ERR_WORKSPACE;
+    }
+    {
+      KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
+      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
+                         acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab, nullptr, NL, MW);
+    }
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((kW * kW / 4 + 63) / 64, NL), dim3(256), 0, s, slab, Pb, kW, kW, kW, 0, kW,
+                       grads, kW, nullptr, 0, 1, deg);
+  }
+  for (int l = kDepth; l < kDepth; ++l) {
+#else
   // Dense_1..7: h_{l-1}^T dz_l  (for l = 5 these are the first 256 input rows)
   for (int l = 1; l < kDepth; ++l) {
+#endif
     {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
 #ifndef PXO_WGRAD_VARIANT

@@ -89,7 +89,6 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--variants" in sys.argv:   # A/B libraries for one GPU session (selected at run time with PXO_LIB)
         build(suffix="_bd2", extra_flags=("-DPXO_BDIST=2",))     # weight fragments fetched 2 k-groups ahead (3 = default)
-        build(suffix="_ws0", extra_flags=("-DPXO_WGRAD_SMALL=0",))       # round-1 skinny weight-gradient kernels
         build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
     if "--variants2" in sys.argv:
         build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
@@ -107,6 +106,3 @@ if __name__ == "__main__":
         build(suffix="_wtrace", extra_flags=("-DPXO_TRACE_WGRAD",))
     if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)
         build(suffix="_abl_nostore", extra_flags=("-DPXO_ABLATE_STORE",))   # fused MLP kernels without the tile copy to HBM
-    if "--wgrad-variants" in sys.argv:
-        for v in (1, 2, 3, 4):
-            build(suffix=f"_w{v}", extra_flags=(f"-DPXO_WGRAD_VARIANT={v}",))

@@ -17,9 +17,6 @@ constexpr int kKC = 32;           // row granularity of the split (rows_per_wg i
 #ifndef PXO_WGRAD_BATCH
 #define PXO_WGRAD_BATCH 1         // 1: Dense_1..7's products in one launch (0: one launch per layer, for A/B)
 #endif
-#ifndef PXO_WGRAD_SMALL
-#define PXO_WGRAD_SMALL 1         // 1: enc-based products fused + head product retiled (0: the round-1 kernels, for A/B)
-#endif
 
 #ifdef PXO_TRACE_WGRAD
 // cycle stamps of wave 0 of workgroup 0 over a few steady-state chunks (timing experiments only): kept in LDS while the
@@ -263,12 +260,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
 __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
                                                           int rows_valid, int col0, int ncols,
                                                           float* __restrict__ dst, int dst_ld,
-                                                          float* __restrict__ dst2, int col0_2,
-                                                          int layer0 = -1, int deg = 0) {
-  if (layer0 >= 0) {               // batched: blockIdx.y = layer group; dst is the gradient arena of the MLP
-    slab += (int64_t)blockIdx.y * P * kin * nout;
-    dst += leaf_kernel_off(layer0 + (int)blockIdx.y, deg);
-  }
+                                                          float* __restrict__ dst2, int col0_2) {
   __shared__ f32x4 red[4][64];
   const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e4 = (int64_t)blockIdx.x * 64 + v;            // float4 index inside one slab
@@ -323,6 +315,77 @@ __global__ void reduce_dbias_kernel(const float* __restrict__ partial, int64_t n
   }
 }
 
+// One launch for every slab reduction of a weight-gradient pass (PXO_WGRAD_BATCH): blockIdx.y selects the job.
+// A job sums P slabs of kin x nout and scatters column ranges A and B of the first rows_valid rows to two leaves.
+struct ReduceJob {
+  const float* slab;
+  int P, kin, nout, rows_valid;
+  float* dst_a; int col0_a, ncols_a, ld_a;
+  float* dst_b; int col0_b, ncols_b, ld_b;      // dst_b == nullptr: no second range
+};
+struct ReduceJobs {
+  ReduceJob job[kDepth + 1];                    // Dense_1..7, enc-based pair (Dense_0 | Dense_5 skip rows), heads
+  const float* dbias_partial;                   // + the bias gradients as job kDepth + 1
+  int64_t dbias_tiles;
+  int deg;
+  float* grads;
+};
+
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs J) {
+  __shared__ f32x4 red[4][64];
+  if (blockIdx.y == kDepth + 1) {               // bias gradients: block = (layer 0..8, 32-column group)
+    if (blockIdx.x >= 9 * 8) return;
+    float (*redb)[32] = reinterpret_cast<float (*)[32]>(&red[0][0]);
+    const int l = blockIdx.x / 8, cg = blockIdx.x % 8;
+    const int c = threadIdx.x & 31, tsub = threadIdx.x >> 5;
+    const int col = cg * 32 + c;
+    float s = 0.f;
+    for (int64_t t = tsub; t < J.dbias_tiles; t += 8) s += J.dbias_partial[(t * 9 + l) * kW + col];
+    redb[tsub][c] = s;
+    __syncthreads();
+    if (tsub == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tot += redb[i][c];
+      if (l < 8) {
+        J.grads[leaf_bias_off(l, J.deg) + col] = tot;
+      } else {
+        const int C = rgb_channels(J.deg);
+        if (col < C) J.grads[leaf_bias_off(9, J.deg) + col] = tot;
+        else if (col == C) J.grads[leaf_bias_off(8, J.deg)] = tot;
+      }
+    }
+    return;
+  }
+  const ReduceJob& j = J.job[blockIdx.y];
+  const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t e4 = (int64_t)blockIdx.x * 64 + v;
+  const int64_t stride4 = (int64_t)j.kin * j.nout / 4;
+  if ((int64_t)blockIdx.x * 64 >= stride4) return;            // whole block past this job's slab
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e4 < stride4) {
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(j.slab) + e4;
+#pragma unroll 8
+    for (int p = q; p < j.P; p += 4) s += src[p * stride4];
+  }
+  red[q][v] = s;
+  __syncthreads();
+  if (q == 0 && e4 < stride4) {
+    f32x4 t = red[0][v];
+    t += red[1][v]; t += red[2][v]; t += red[3][v];
+    const int64_t e = e4 * 4;
+    const int i = (int)(e / j.nout), n0 = (int)(e % j.nout);
+    if (i < j.rows_valid) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = n0 + k;
+        if (n >= j.col0_a && n < j.col0_a + j.ncols_a) j.dst_a[(int64_t)i * j.ld_a + (n - j.col0_a)] = t[k];
+        else if (j.dst_b && n >= j.col0_b && n < j.col0_b + j.ncols_b) j.dst_b[(int64_t)i * j.ld_b + (n - j.col0_b)] = t[k];
+      }
+    }
+  }
+}
+
 static void split_rows(int64_t M, int64_t target, int64_t* rows_per_wg, int* P) {
   int64_t rpw = (M + target - 1) / target;
   rpw = (rpw + kKC - 1) / kKC * kKC;
@@ -337,7 +400,9 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
   // different M share one workspace)
   (void)cfg; (void)M;
 #if PXO_WGRAD_BATCH
-  return (size_t)(kDepth - 1) * num_cus() * kW * kW * sizeof(float);     // Dense_1..7 in one launch: a slab set per layer
+  // Dense_1..7 in one launch: a slab set per layer; then the enc-based pair's and the heads' slabs (all reduced together)
+  return ((size_t)(kDepth - 1) * num_cus() * kW * kW + (size_t)2 * num_cus() * kEncPad * 2 * kW +
+          (size_t)2 * num_cus() * kW * 32 * 3) * sizeof(float);
 #else
   return (size_t)num_cus() * kW * kW * sizeof(float);
 #endif
@@ -346,15 +411,10 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
 template <int NHB>
 static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const float* d_raw_sigma, int C,
                               int64_t M, int64_t rpw, int P, float* slab, hipStream_t s) {
-#if PXO_WGRAD_SMALL == 0
-  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 8, 1, true, 512, 32, 1>), dim3(P), dim3(512), 0, s, X, d_raw_rgb,
-                     d_raw_sigma, C, M, rpw, P, slab);
-#else
   // 4 waves, each 64 rows x all head columns (4 LDS operand reads per 4 MFMAs instead of 3 per 2), 40 KB of LDS:
   // several workgroups per CU
   hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
                      d_raw_sigma, C, M, rpw, P, slab);
-#endif
 }
 
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
@@ -364,126 +424,102 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   if (M == 0) return PXO_OK;
   const int deg = cfg->sh_deg;
   const int C = rgb_channels(deg);
-  int64_t rpw; int P;
-  split_rows(M, num_cus(), &rpw, &P);
-  int64_t rpw2; int P2;                      // the skinny products: two workgroups per CU
-#if PXO_WGRAD_SMALL == 0
-  split_rows(M, num_cus(), &rpw2, &P2);
-#else
+  const int nhb = head_blocks(deg);
+  const int64_t MW = M * kW;
+  constexpr int NL = kDepth - 1;
+  (void)NL;
+  if (ws_bytes < wgrad_workspace_bytes(cfg, M)) {
+    set_error("wgrad workspace too small: %zu < %zu", ws_bytes, wgrad_workspace_bytes(cfg, M));
+    return PXO_ERR_WORKSPACE;
+  }
+  // the skinny products (enc-based pair, heads): two workgroups per CU (256 / 128 ranges measured equal or slower at
+  // 4096, 1024 and 512 rays per step)
+  int64_t rpw2; int P2;
   {
     static const int ranges2_override = getenv("PXO_WGRAD_RANGES2") ? atoi(getenv("PXO_WGRAD_RANGES2")) : 0;   // A/B hook
     split_rows(M, ranges2_override > 0 && ranges2_override <= 2 * num_cus() ? ranges2_override : 2 * (int64_t)num_cus(),
                &rpw2, &P2);
   }
-#endif
-  if (ws_bytes < (size_t)P * kW * kW * sizeof(float) || ws_bytes < (size_t)P2 * kEncPad * 2 * kW * sizeof(float)) {
-    set_error("wgrad workspace too small: %zu < %zu", ws_bytes, (size_t)P * kW * kW * sizeof(float));
-    return PXO_ERR_WORKSPACE;
+  const float* h7 = acts + (int64_t)7 * MW;
+  auto head = [&](float* slab) {
+    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
+    if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+    else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+    else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+  };
+  // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
+  auto enc_pair = [&](float* slab) {
+    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
+    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
+                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
+  };
+  float* const g0 = grads + leaf_kernel_off(0, deg);
+  float* const g5skip = grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW;
+  float* const g8 = grads + leaf_kernel_off(8, deg);
+  float* const g9 = grads + leaf_kernel_off(9, deg);
+#if PXO_WGRAD_BATCH
+  // Dense_1..7: h_{l-1}^T dz_l (for l = 5 these are the first 256 input rows) in ONE launch: acts and dz are [8][M,256]
+  // stacks, so layer l is "group l-1" of the kernel with layer_stride = M*256; then ONE launch reduces every slab set of
+  // the pass (and the bias partials).  14 + 12 launches per step fewer than a launch per product, and the layers'
+  // ramp-ups and tails overlap.
+  // Row ranges per layer: the grid is NL x ranges x 2 column halves on 2 num_cus() slots, all of equal work, so whole
+  // "waves" of workgroups are what to aim for: num_cus() ranges = NL waves; 4 num_cus() / NL = 4 waves.  Measured
+  // (rays/s at 4096 / 1024 / 512 rays per step, 256 CUs): 256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k /
+  // 144.3 k / 127.9 k (one launch per layer: 159.7 k / 139.9 k / 120.3 k) - long ranges lose on big passes (the two
+  // column halves drift apart and the shared operand stops hitting L2), short ones pay 64 MB of slab traffic per layer.
+  static const int ranges_override = getenv("PXO_WGRAD_RANGES") ? atoi(getenv("PXO_WGRAD_RANGES")) : 0;   // A/B hook
+  int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
+  if (ranges_override > 0 && ranges_override <= num_cus()) ranges = ranges_override;
+  int64_t rpwb; int Pb;
+  split_rows(M, ranges, &rpwb, &Pb);
+  float* const slab_main = reinterpret_cast<float*>(ws);
+  float* const slab_enc = slab_main + (size_t)NL * num_cus() * kW * kW;
+  float* const slab_head = slab_enc + (size_t)2 * num_cus() * kEncPad * 2 * kW;
+  enc_pair(slab_enc);
+  {
+    KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
+    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
+                       acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW);
   }
+  head(slab_head);
+  ReduceJobs J;
+  for (int l = 1; l < kDepth; ++l)
+    J.job[l - 1] = ReduceJob{slab_main + (size_t)(l - 1) * Pb * kW * kW, Pb, kW, kW, kW,
+                             grads + leaf_kernel_off(l, deg), 0, kW, kW, nullptr, 0, 0, 0};
+  J.job[NL] = ReduceJob{slab_enc, P2, kEncPad, 2 * kW, kEnc, g0, 0, kW, kW, g5skip, kW, kW, kW};
+  J.job[NL + 1] = ReduceJob{slab_head, P2, kW, 32 * nhb, kW, g9, 0, C, C, g8, C, 1, 1};
+  J.dbias_partial = dbias_partial;
+  J.dbias_tiles = (int64_t)mlp_bwd_partials(M);
+  J.deg = deg;
+  J.grads = grads;
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3(kW * kW / 4 / 64, kDepth + 2), dim3(256), 0, s, J);
+#else
+  // one launch per product, each followed by its slab reduce (round 2a; kept for A/B)
   float* slab = reinterpret_cast<float*>(ws);
-  const int64_t MW = M * kW;
+  int64_t rpw; int P;
+  split_rows(M, num_cus(), &rpw, &P);
   auto reduce2 = [&](int np, int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld, float* dst2,
                      int col0_2) {
     const int n4 = kin * nout / 4;
     hipLaunchKernelGGL(reduce_slab_kernel, dim3((n4 + 63) / 64), dim3(256), 0, s, slab, np, kin, nout,
                        rows_valid, col0, ncols, dst, dst_ld, dst2, col0_2);
   };
-  auto reduce = [&](int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld) {
-    reduce2(P, kin, nout, rows_valid, col0, ncols, dst, dst_ld, nullptr, 0);
-  };
-#if PXO_WGRAD_SMALL == 0
-  // Dense_0: enc^T dz_0  (63 valid input rows)
-  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc, dz,
-                     nullptr, 0, M, rpw, P, slab);
-  reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW);
-#else
-  // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
-  {
-    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
-    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
-                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
-  }
-  reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, grads + leaf_kernel_off(0, deg), kW,
-          grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
-#endif
-#if PXO_WGRAD_BATCH
-  // Dense_1..7: h_{l-1}^T dz_l (for l = 5 these are the first 256 input rows) in ONE launch: acts and dz are [8][M,256]
-  // stacks, so layer l is "group l-1" of the kernel with layer_stride = M*256.  The row ranges are 7x longer than with a
-  // launch per layer (same number of workgroups in flight), i.e. 1/7 of the slab traffic and of the ramp-up/tail, and
-  // 2 launches instead of 14 - what small batches (rays/GPU of the strong-scaling shape) pay most for.
-  {
-    constexpr int NL = kDepth - 1;
-    int64_t rpwb; int Pb;
-    // Row ranges per layer: the grid is NL x ranges x 2 column halves on 2 num_cus() slots, all of equal work, so whole
-    // "waves" of workgroups are what to aim for: num_cus() ranges = NL waves; 4 num_cus() / NL = 4 waves.  Measured
-    // (rays/s at 4096 / 1024 / 512 rays per step, 256 CUs): 256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k /
-    // 144.3 k / 127.9 k (one launch per layer: 159.7 k / 139.9 k / 120.3 k) - long ranges lose on big passes (the two
-    // column halves drift apart and the shared operand stops hitting L2), short ones pay 64 MB of slab traffic per layer.
-    static const int ranges_override = getenv("PXO_WGRAD_RANGES") ? atoi(getenv("PXO_WGRAD_RANGES")) : 0;   // A/B hook
-    int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
-    if (ranges_override > 0 && ranges_override <= num_cus()) ranges = ranges_override;
-    split_rows(M, ranges, &rpwb, &Pb);
-    if (ws_bytes < (size_t)NL * Pb * kW * kW * sizeof(float)) {
-      set_error("wgrad workspace too small: %zu < %zu", ws_bytes, (size_t)NL * Pb * kW * kW * sizeof(float));
-      return PXO_ERR_WORKSPACE;
-    }
-    {
-      KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
-      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
-                         acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab, nullptr, NL, MW);
-    }
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((kW * kW / 4 + 63) / 64, NL), dim3(256), 0, s, slab, Pb, kW, kW, kW, 0, kW,
-                       grads, kW, nullptr, 0, 1, deg);
-  }
-  for (int l = kDepth; l < kDepth; ++l) {
-#else
-  // Dense_1..7: h_{l-1}^T dz_l  (for l = 5 these are the first 256 input rows)
+  enc_pair(slab);
+  reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, g0, kW, g5skip, kW);
   for (int l = 1; l < kDepth; ++l) {
-#endif
     {
-    KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
-#ifndef PXO_WGRAD_VARIANT
-#define PXO_WGRAD_VARIANT 0
-#endif
-#if PXO_WGRAD_VARIANT == 1     // one 8-wave workgroup per CU, 32-row chunks, no column split
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 2, false, 512, 32, 1>), dim3(P), dim3(512), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-#elif PXO_WGRAD_VARIANT == 2   // 4-way column split: 256 x 64 per workgroup, up to 4 workgroups per CU
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 4>), dim3(((P + 7) / 8) * 32), dim3(256), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-#elif PXO_WGRAD_VARIANT == 3   // 2-way split, waves tiled 4 x 1 (64 rows x 128 cols each)
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 4, 1, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-#elif PXO_WGRAD_VARIANT == 4   // 2-way split, 32-row chunks (one workgroup per CU by LDS)
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 32, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-#else
-    // 256x256 product as two independent 4-wave workgroups per CU (256 x 128 each, 16-row chunks)
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
-                       acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-#endif
+      KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
+      // 256x256 product as two independent 4-wave workgroups per CU (256 x 128 each, 16-row chunks)
+      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
+                         acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
     }
-    reduce(kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW);
+    reduce2(P, kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW, nullptr, 0);
   }
-#if PXO_WGRAD_SMALL == 0
-  // Dense_5 skip rows 256..318: enc^T dz_5
-  hipLaunchKernelGGL((wgrad_kernel<kEncPad, kW, 2, 4, false, 512, 32, 1>), dim3(P), dim3(512), 0, s, enc,
-                     dz + (int64_t)5 * MW, nullptr, 0, M, rpw, P, slab);
-  reduce(kEncPad, kW, kEnc, 0, kW, grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW, kW);
-#endif
-  // heads: h7^T [d_raw_rgb | d_raw_sigma]
-  const float* h7 = acts + (int64_t)7 * MW;
-  const int nhb = head_blocks(deg);
-  {
-    KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
-    if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
-    else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
-    else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
-  }
-  reduce2(P2, kW, 32 * nhb, kW, 0, C, grads + leaf_kernel_off(9, deg), C, nullptr, 0);
-  reduce2(P2, kW, 32 * nhb, kW, C, 1, grads + leaf_kernel_off(8, deg), 1, nullptr, 0);
-  // biases
+  head(slab);
+  reduce2(P2, kW, 32 * nhb, kW, 0, C, g9, C, nullptr, 0);
+  reduce2(P2, kW, 32 * nhb, kW, C, 1, g8, 1, nullptr, 0);
   hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, (int64_t)mlp_bwd_partials(M), deg, grads);
+#endif
   return check_launch("mlp_bwd_weights");
 }
 

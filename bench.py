@@ -42,6 +42,9 @@ def parse(argv=None):
     p.add_argument("--preset", choices=["blender", "tt"], default="blender")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the tt_sh25 / render_fwd / grid512 records")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise RCCL and issue the per-step collectives even with one rank (exercises the "
+                        "multi-GPU code path on a 1-GPU box)")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
     p.add_argument("--cpu-steps", type=int, default=8)
     return p.parse_args(argv)
@@ -149,10 +152,11 @@ class Job:
         self.device = torch.device("cuda", self.local_rank)
         self.dist = None
         self.ranks_seen = 1
-        if self.world > 1:
+        if self.world > 1 or getattr(a, "force_dist", False):
             import torch.distributed as dist_mod
             self.dist = dist_mod
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
             self.dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
                                          device_id=self.device)                    # RCCL over xGMI
             one = torch.ones(1, device=self.device)
@@ -382,7 +386,7 @@ def main():
                                    "800x800 synthetic views, sparsity 10k pts, Adam",
                        "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
                        "parallelism": f"dp{world}"},
-            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": 1 if world > 1 else 0,
+            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": 1 if job.dist else 0,
             "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
             "final_stats": tr["stats"],
             "roofline": roofline, "kernels": kernels,

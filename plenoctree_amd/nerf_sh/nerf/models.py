@@ -138,8 +138,9 @@ def train_step(model, state, batch, lr, randomized=True, t_rand=None, u=None, sp
                       state.grads, state.stats, ws, randomized=randomized, t_rand=t_rand, u=u, sp_points=sp_points,
                       seed=seed)
     scale = 1.0
+    if all_reduce is not None:
+        all_reduce(state.reduce_buf)        # gradients + stats, one RCCL call (a no-op Comm at world size 1)
     if world_size > 1:
-        all_reduce(state.reduce_buf)        # gradients + stats, one RCCL call
         state.stats.mul_(1.0 / world_size)
         scale = 1.0 / world_size
     ops.adam_step(state.params, state.m, state.v, state.grads, lr, state.step, grad_scale=scale)

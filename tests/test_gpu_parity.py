@@ -853,3 +853,24 @@ def test_eval_points_past_2g_output_elements():
     rgb_s, sig_s = ops.eval_points(pcfg, pf, pts[pick].contiguous())
     assert torch.equal(rgb[pick], rgb_s) and torch.equal(sig[pick], sig_s)
     assert bool(torch.isfinite(sig).all())
+
+
+def test_bench_collective_path_through_rccl_single_rank():
+    """The multi-GPU leg of bench.py on this 1-GPU box: launched the way the driver launches N > 1 (torch.distributed.run,
+    one rank per GPU) with --force-dist, so the process group is RCCL and every step issues its one all-reduce of
+    [gradients | stats] on the device; the throughput line must come out as without it."""
+    _gpu()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--batch", "1024", "--no-cpu-baseline", "--no-extras", "--force-dist"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["nccl_ranks_seen"] == 1 and out["collectives_per_step"] == 1
+    assert out["value"] > 5e4 and np.isfinite(out["final_stats"]["loss"])

@@ -99,6 +99,8 @@ if __name__ == "__main__":
             build(suffix=f"_x3a{a}", extra_flags=(f"-DPXO_X3_ABL={a}",))
     if "--wgrad-batch" in sys.argv:
         build(suffix="_wb0", extra_flags=("-DPXO_WGRAD_BATCH=0",))       # one 256x256 wgrad launch per layer (round-2a)
+    if "--oct-vec" in sys.argv:
+        build(suffix="_ovec0", extra_flags=("-DPXO_OCT_VEC=0",))         # forward renderer with dword coefficient loads
     if "--oct-ablations" in sys.argv:  # timing only, results wrong: octree backward without / with plain-store scatter
         for a in (1, 2, 3):
             build(suffix=f"_octa{a}", extra_flags=(f"-DPXO_OCT_ABL={a}",))

@@ -426,14 +426,19 @@ constexpr int kRenderThreads = 256;
 #ifndef PXO_OCT_ABL
 #define PXO_OCT_ABL 0
 #endif
+#ifndef PXO_OCT_VEC
+#define PXO_OCT_VEC 1             // forward renderer: leaf coefficients as 16-byte loads per lane (0: one dword per lane per load)
+#endif
 // lanes per ray: ROW in {4, 8, 16}; the wave carries 64/ROW rays as a WTX x WTY pixel patch
 template <int ROW> struct RowGeom {
   static constexpr int kRaysPerWave = 64 / ROW;
   static constexpr int kRaysPerBlock = kRenderThreads / ROW;
-  static constexpr int kWTX = kRaysPerWave == 4 ? 2 : 4;
+  static constexpr int kWTX = kRaysPerWave <= 4 ? 2 : (kRaysPerWave <= 16 ? 4 : 8);
   static constexpr int kWTY = kRaysPerWave / kWTX;
   static constexpr int kMaxLoads = (75 + ROW - 1) / ROW;      // SH25: 75 coefficients
+  static constexpr int kMaxGroups = (19 + ROW - 1) / ROW;     // ... as 19 groups of 4 consecutive floats
 };
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a leaf row is only 4-byte aligned (49 floats)
 
 template <int ROW>
 __device__ __forceinline__ float row_sum(float v) {   // sum over the ROW lanes of a ray, result in every lane
@@ -507,7 +512,10 @@ struct Marcher {
 };
 
 // MODE 0: forward (writes out_rgb).  MODE 1: gradient w.r.t. tree data (two marches per ray).
-template <int MODE, int ROW>
+// VEC (forward only): lane l owns the float groups l, l+ROW, ... (4 consecutive data indices each) instead of the single
+// indices l, l+ROW, ...: a leaf's coefficients arrive in ceil(3K/4/ROW) 16-byte loads per lane (SH16, 8 lanes: 2 instead
+// of 6 dword loads).  For every SH format 3K+1 is 0 or 1 mod 4, so the last group never leaves the leaf's own row.
+template <int MODE, int ROW, bool VEC = false>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArgs A, float* __restrict__ out_rgb,
                                                                         const float* __restrict__ fwd_rgb,
                                                                         const float* __restrict__ grad_out,
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
   const bool miss = r.tmax < 0.0f || r.tmin > r.tmax;
   if (MODE == 0 && miss) {
-    if (l < 3) out_rgb[ray * 3 + l] = bg;
+    for (int c = l; c < 3; c += kRow) out_rgb[ray * 3 + c] = bg;
     return;
   }
   if (MODE == 1 && miss) return;
@@ -562,14 +570,16 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   // per-lane channel ownership: data index l + ROW j -> (channel, SH component)
   if (l == 0) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
   __builtin_amdgcn_wave_barrier();
-  const int nload = (D - 1 + kRow - 1) / kRow;
-  float b0[kMaxLoads], b1[kMaxLoads], b2[kMaxLoads];
+  static_assert(!VEC || MODE == 0, "vector loads: forward only (the gradient scatter wants contiguous dword rows)");
+  constexpr int kSlots = VEC ? G::kMaxGroups * 4 : kMaxLoads;       // data elements owned by a lane
+  const int nload = VEC ? ((D - 1 + 3) / 4 + kRow - 1) / kRow : (D - 1 + kRow - 1) / kRow;   // loads per lane in use
+  float b0[kSlots], b1[kSlots], b2[kSlots];
 #pragma unroll
-  for (int j = 0; j < kMaxLoads; ++j) {
-    const int idx = l + kRow * j;
+  for (int j = 0; j < kSlots; ++j) {
+    const int idx = VEC ? 4 * (l + kRow * (j >> 2)) + (j & 3) : l + kRow * j;
     float bas = 0.0f;
     int ch = -1;
-    if (j < nload && idx < D - 1) {
+    if ((VEC ? (j >> 2) : j) < nload && idx < D - 1) {
       ch = idx / K;
       bas = s_basis[row][idx - ch * K];
     }
@@ -625,14 +635,31 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
         const float att = expf(-dtw * sg);
         const float weight = light * (1.0f - att);
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        if (VEC) {
 #pragma unroll
-        for (int j = 0; j < kMaxLoads; ++j) {
-          if (j < nload) {
-            const int idx = l + kRow * j;
-            const float v = idx < D - 1 ? val[idx] : 0.0f;
-            p0 += v * b0[j];
-            p1 += v * b1[j];
-            p2 += v * b2[j];
+          for (int j = 0; j < G::kMaxGroups; ++j) {
+            const int g4 = 4 * (l + kRow * j);
+            if (j < nload && g4 < D - 1) {
+              const f32x4u v4 = *reinterpret_cast<const f32x4u*>(val + g4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = g4 + e < D - 1 ? v4[e] : 0.0f;          // the row's last float is sigma, not a coefficient
+                p0 += v * b0[4 * j + e];
+                p1 += v * b1[4 * j + e];
+                p2 += v * b2[4 * j + e];
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kMaxLoads; ++j) {
+            if (j < nload) {
+              const int idx = l + kRow * j;
+              const float v = idx < D - 1 ? val[idx] : 0.0f;
+              p0 += v * b0[j];
+              p1 += v * b1[j];
+              p2 += v * b2[j];
+            }
           }
         }
         p0 = row_sum<ROW>(p0);
@@ -687,7 +714,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
         if (!stopped) {
           out[0] += light * bg; out[1] += light * bg; out[2] += light * bg;
         }
-        if (l < 3) out_rgb[ray * 3 + l] = l == 0 ? out[0] : (l == 1 ? out[1] : out[2]);
+        for (int c = l; c < 3; c += kRow) out_rgb[ray * 3 + c] = c == 0 ? out[0] : (c == 1 ? out[1] : out[2]);
       } else {
         accum = (g[0] * (out[0] + light * bg) + g[1] * (out[1] + light * bg)) + g[2] * (out[2] + light * bg);
       }
@@ -924,7 +951,10 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // forward 3.88 / 3.36 / 4.23 ms for 16 / 8 / 4 lanes (8 lanes: twice the rays in flight per wave, half the
 // duplicated traversal arithmetic, coefficient rows still 32-byte coalesced); backward 10.9 / 14.0 / 22.1 ms (the
 // gradient scatter wants the widest atomic rows); SH25: forward 4.34 / 4.04 ms, backward 13.9 / 17.8 ms for 16 / 8.
-// So: forward 8 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+// With the forward kernel's 16-byte coefficient loads (round 2: a lane owns groups of 4 consecutive floats) the balance
+// moves to fewer lanes: forward 3.51 / 2.98 / 2.44 ms for 16 / 8 / 4 lanes (dword loads: 3.88 / 3.11 / 4.23), SH25 3.45 /
+// 3.06 ms for 8 / 4, SH9 2.14 ms at 4; 2 lanes measured slower again (3.25 ms).
+// So: forward 4 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
 static int g_row_override[2] = {0, 0};   // [forward, backward]; 0 = the measured default
 static int render_row(bool backward, int data_dim) {
   static const int forced = [] {
@@ -935,7 +965,7 @@ static int render_row(bool backward, int data_dim) {
   if (g_row_override[backward ? 1 : 0]) return g_row_override[backward ? 1 : 0];
   if (forced) return forced;
   (void)data_dim;
-  return backward ? 16 : 8;
+  return backward ? 16 : 4;
 }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
@@ -959,7 +989,7 @@ static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* o
     PXO_REQUIRE(B == (int64_t)cam->width * cam->height, "%s: B must be width*height in camera mode", who);
     A.cam = *cam;
     A.origins = A.dirs = A.viewdirs = nullptr;
-    const int rpw = 64 / row, tx = 2 * (rpw == 4 ? 2 : 4), ty = 2 * (rpw / (rpw == 4 ? 2 : 4));
+    const int rpw = 64 / row, wtx = rpw <= 4 ? 2 : (rpw <= 16 ? 4 : 8), tx = 2 * wtx, ty = 2 * (rpw / wtx);
     blocks = (int64_t)((cam->width + tx - 1) / tx) * ((cam->height + ty - 1) / ty);
   } else {
     PXO_REQUIRE(B == 0 || (origins && dirs && viewdirs), "%s: null ray arrays", who);
@@ -990,9 +1020,9 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
   PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
   const float* none = nullptr;
   switch (row) {
-    case 4: hipLaunchKernelGGL((octree_render_kernel<0, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
-    case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
-    default: hipLaunchKernelGGL((octree_render_kernel<0, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    case 4: hipLaunchKernelGGL((octree_render_kernel<0, 4, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    default: hipLaunchKernelGGL((octree_render_kernel<0, 16, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
   }
   return check_launch("octree_render_fwd");
 }

@@ -22,7 +22,7 @@ if [ "${DO_BENCH:-1}" = "1" ]; then
 fi
 if [ "${DO_PROF:-0}" = "1" ]; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras ${PROF_ARGS:-} > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
   echo "rocprof exit $?"
   i=0
   [ "${DO_PMC:-0}" = "1" ] && for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do

@@ -239,12 +239,12 @@ def test_octree_render_gradient_matches_oracle(K):
 
 @pytest.mark.parametrize("lanes", [4, 8, 16])
 def test_octree_render_every_lanes_per_ray_template(lanes):
-    """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 8 forward / 16 backward);
-    every instantiation is held to the same oracle bounds, forward and gradient, for SH16 and SH25."""
+    """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 4 forward / 16 backward);
+    every instantiation is held to the same oracle bounds, forward and gradient, for every SH format."""
     oops = _oops(); dev = _gpu()
     try:
         oops.set_lanes_per_ray(lanes, lanes)
-        for K in (16, 25):
+        for K in (1, 4, 9, 16, 25):
             t = _random_tree(3, 50 + K, K)
             view, (child, data) = _device_tree(t, dev)
             W, H, fx = 13, 9, 12.0

@@ -99,6 +99,9 @@ if __name__ == "__main__":
             build(suffix=f"_x3a{a}", extra_flags=(f"-DPXO_X3_ABL={a}",))
     if "--wgrad-batch" in sys.argv:
         build(suffix="_wb0", extra_flags=("-DPXO_WGRAD_BATCH=0",))       # one 256x256 wgrad launch per layer (round-2a)
+    if "--oct-k16" in sys.argv:
+        build(suffix="_ok16_0", extra_flags=("-DPXO_OCT_K16=0",))        # forward renderer without the SH16 fast path
+        build(suffix="_och0", extra_flags=("-DPXO_OCT_CH=0", "-DPXO_OCT_K16=0"))   # ... and without channel-aligned ownership
     if "--oct-vec" in sys.argv:
         build(suffix="_ovec0", extra_flags=("-DPXO_OCT_VEC=0",))         # forward renderer with dword coefficient loads
     if "--oct-ablations" in sys.argv:  # timing only, results wrong: octree backward without / with plain-store scatter

@@ -426,6 +426,12 @@ constexpr int kRenderThreads = 256;
 #ifndef PXO_OCT_ABL
 #define PXO_OCT_ABL 0
 #endif
+#ifndef PXO_OCT_CH
+#define PXO_OCT_CH 1              // forward renderer at 4 lanes per ray: channel-aligned coefficient ownership for every K (0: A/B)
+#endif
+#ifndef PXO_OCT_K16
+#define PXO_OCT_K16 1             // ... with K a compile-time constant per SH format (0: run-time K, for A/B)
+#endif
 #ifndef PXO_OCT_VEC
 #define PXO_OCT_VEC 1             // forward renderer: leaf coefficients as 16-byte loads per lane (0: one dword per lane per load)
 #endif
@@ -515,7 +521,12 @@ struct Marcher {
 // VEC (forward only): lane l owns the float groups l, l+ROW, ... (4 consecutive data indices each) instead of the single
 // indices l, l+ROW, ...: a leaf's coefficients arrive in ceil(3K/4/ROW) 16-byte loads per lane (SH16, 8 lanes: 2 instead
 // of 6 dword loads).  For every SH format 3K+1 is 0 or 1 mod 4, so the last group never leaves the leaf's own row.
-template <int MODE, int ROW, bool VEC = false>
+// KF != 0 (forward, VEC): channel-aligned ownership.  Per colour channel, lane l owns the float4 groups l, l+ROW, .. of the
+// K/4 whole groups and coefficient 4 (K/4) + l of the K % 4 left over, so the basis values a lane needs are the same for
+// the three channels: 4 ceil(K/4/ROW) + 1 registers instead of a selector-weighted triple per data element, and a third
+// of the FMAs.  KF = K (1, 4, 9, 16, 25) makes K a compile-time constant (SH16 at 4 lanes: one float4 per lane and channel,
+// 56 VGPRs - 8 waves per SIMD - against 112 for the index-ordered path); KF = -1 keeps it a run-time value.
+template <int MODE, int ROW, bool VEC = false, int KF = 0>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArgs A, float* __restrict__ out_rgb,
                                                                         const float* __restrict__ fwd_rgb,
                                                                         const float* __restrict__ grad_out,
@@ -571,7 +582,19 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   if (l == 0) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
   __builtin_amdgcn_wave_barrier();
   static_assert(!VEC || MODE == 0, "vector loads: forward only (the gradient scatter wants contiguous dword rows)");
-  constexpr int kSlots = VEC ? G::kMaxGroups * 4 : kMaxLoads;       // data elements owned by a lane
+  static_assert(KF == 0 || (VEC && MODE == 0), "channel-aligned paths: forward, vector loads");
+  const int Kc = KF > 0 ? KF : K;                    // compile-time when the launch is specialised for the tree's format
+  constexpr int kChM = ((KF > 0 ? KF / 4 : 6) + ROW - 1) / ROW > 0 ? ((KF > 0 ? KF / 4 : 6) + ROW - 1) / ROW : 1;   // K <= 25: <= 6 whole groups
+  const int chG = Kc >> 2, chR = Kc & 3;
+  float bk[4 * kChM], bk_r = 0.0f;
+  if (KF != 0) {
+#pragma unroll
+    for (int m = 0; m < kChM; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bk[4 * m + e] = (l + kRow * m) < chG ? s_basis[row][4 * (l + kRow * m) + e] : 0.0f;
+    if (l < chR) bk_r = s_basis[row][4 * chG + l];
+  }
+  constexpr int kSlots = KF ? 1 : (VEC ? G::kMaxGroups * 4 : kMaxLoads);       // data elements owned by a lane (generic paths)
   const int nload = VEC ? ((D - 1 + 3) / 4 + kRow - 1) / kRow : (D - 1 + kRow - 1) / kRow;   // loads per lane in use
   float b0[kSlots], b1[kSlots], b2[kSlots];
 #pragma unroll
@@ -579,7 +602,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     const int idx = VEC ? 4 * (l + kRow * (j >> 2)) + (j & 3) : l + kRow * j;
     float bas = 0.0f;
     int ch = -1;
-    if ((VEC ? (j >> 2) : j) < nload && idx < D - 1) {
+    if (KF == 0 && (VEC ? (j >> 2) : j) < nload && idx < D - 1) {
       ch = idx / K;
       bas = s_basis[row][idx - ch * K];
     }
@@ -635,7 +658,29 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
         const float att = expf(-dtw * sg);
         const float weight = light * (1.0f - att);
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-        if (VEC) {
+        if (KF != 0) {
+#pragma unroll
+          for (int m = 0; m < kChM; ++m) {
+            const int g = l + kRow * m;
+            if (g < chG) {
+              const f32x4u c0 = *reinterpret_cast<const f32x4u*>(val + 4 * g);
+              const f32x4u c1 = *reinterpret_cast<const f32x4u*>(val + Kc + 4 * g);
+              const f32x4u c2 = *reinterpret_cast<const f32x4u*>(val + 2 * Kc + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                p0 += c0[e] * bk[4 * m + e];
+                p1 += c1[e] * bk[4 * m + e];
+                p2 += c2[e] * bk[4 * m + e];
+              }
+            }
+          }
+          if (l < chR) {
+            const int k = 4 * chG + l;
+            p0 += val[k] * bk_r;
+            p1 += val[Kc + k] * bk_r;
+            p2 += val[2 * Kc + k] * bk_r;
+          }
+        } else if (VEC) {
 #pragma unroll
           for (int j = 0; j < G::kMaxGroups; ++j) {
             const int g4 = 4 * (l + kRow * j);
@@ -953,7 +998,8 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // gradient scatter wants the widest atomic rows); SH25: forward 4.34 / 4.04 ms, backward 13.9 / 17.8 ms for 16 / 8.
 // With the forward kernel's 16-byte coefficient loads (round 2: a lane owns groups of 4 consecutive floats) the balance
 // moves to fewer lanes: forward 3.51 / 2.98 / 2.44 ms for 16 / 8 / 4 lanes (dword loads: 3.88 / 3.11 / 4.23), SH25 3.45 /
-// 3.06 ms for 8 / 4, SH9 2.14 ms at 4; 2 lanes measured slower again (3.25 ms).
+// 3.06 ms for 8 / 4, SH9 2.14 ms at 4; 2 lanes measured slower again (3.25 ms).  At 4 lanes the channel-aligned ownership
+// with compile-time K (KF) then takes SH16 to 1.61 ms, SH25 to 2.35 ms, SH9 to 1.75 ms.
 // So: forward 4 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
 static int g_row_override[2] = {0, 0};   // [forward, backward]; 0 = the measured default
 static int render_row(bool backward, int data_dim) {
@@ -1020,7 +1066,22 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
   PXO_REQUIRE(out_rgb, "pxo_octree_render_fwd: null output");
   const float* none = nullptr;
   switch (row) {
-    case 4: hipLaunchKernelGGL((octree_render_kernel<0, 4, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    case 4:
+#define PXO_FWD4(KF_) hipLaunchKernelGGL((octree_render_kernel<0, 4, PXO_OCT_VEC != 0, KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr)
+      if (PXO_OCT_VEC != 0 && PXO_OCT_CH != 0) {
+        switch (PXO_OCT_K16 != 0 ? tree->basis_dim : 0) {
+          case 1: PXO_FWD4(1); break;
+          case 4: PXO_FWD4(4); break;
+          case 9: PXO_FWD4(9); break;
+          case 16: PXO_FWD4(16); break;
+          case 25: PXO_FWD4(25); break;
+          default: PXO_FWD4(-1); break;
+        }
+      } else {
+        PXO_FWD4(0);
+      }
+#undef PXO_FWD4
+      break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
     default: hipLaunchKernelGGL((octree_render_kernel<0, 16, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
   }

@@ -109,7 +109,7 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
  *      octree/optimization.py:174-216) ---- */
 
 /* Lanes of a wave that cooperate on one ray in the forward / backward renderer launches: 4, 8 or 16, or 0 for
- * the measured default (4 forward, 16 backward).  A tuning knob (results are identical up to the SH summation
+ * the measured default (4 both ways; backward at 4 = 4-lane march with a 16-lane cooperative gradient scatter).  A tuning knob (results are identical up to the SH summation
  * order); process-wide. */
 int pxo_octree_set_lanes_per_ray(int forward, int backward);
 

@@ -426,6 +426,9 @@ constexpr int kRenderThreads = 256;
 #ifndef PXO_OCT_ABL
 #define PXO_OCT_ABL 0
 #endif
+#ifndef PXO_OCT_BWD4
+#define PXO_OCT_BWD4 1            // backward at "4 lanes per ray": 4-lane march + 16-lane cooperative scatter (0: the plain 4-lane kernel)
+#endif
 #ifndef PXO_OCT_CH
 #define PXO_OCT_CH 1              // forward renderer at 4 lanes per ray: channel-aligned coefficient ownership for every K (0: A/B)
 #endif
@@ -770,6 +773,202 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
 #endif
 }
 
+// Backward with a 4-lane march and a 16-lane scatter (PXO_OCT_BWD4).  The march is the forward kernel's: 16 rays per wave,
+// channel-aligned coefficient reads, few registers - the phase that is latency-bound.  The scatter wants the opposite shape
+// (the gradient of a sample is a 3K-float row: 64-byte atomic rows per instruction), so after every march step the wave
+// re-deals itself as 4 rays x 16 lanes, four times: lane (q, j) of deal g fetches the step's row-uniform results of ray
+// 4g + q from that ray's lanes (shfl) and adds basis_k(ray) * d_channel at the data indices j, j + 16, .. - the same 64-byte rows per
+// instruction as the 16-lane kernel, with the march running at four times its rays per wave.  Rays that have finished stay in
+// the loop (idle) until the whole wave is done, since every lane takes part in every deal.
+template <int KF>
+__global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(RenderArgs A, const float* __restrict__ fwd_rgb,
+                                                                             const float* __restrict__ grad_out,
+                                                                             float* __restrict__ grad_data) {
+  using G = RowGeom<4>;
+  constexpr int kRow = 4, kRaysPerBlock = G::kRaysPerBlock;
+  __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
+  __shared__ float s_basis[kRaysPerBlock][25];
+  const int row = threadIdx.x / kRow, l = threadIdx.x % kRow, lane = threadIdx.x & 63;
+  int64_t ray = 0;
+  float origin[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f}, vdir[3] = {0.f, 0.f, 1.f};
+  bool active = true;
+  if (A.has_cam) {
+    const int W = A.cam.width, H = A.cam.height;
+    const int tiles_x = (W + 2 * G::kWTX - 1) / (2 * G::kWTX);
+    const int bx = (int)(blockIdx.x % tiles_x), by = (int)(blockIdx.x / tiles_x);
+    const int wv = row / G::kRaysPerWave, q = row % G::kRaysPerWave;
+    const int px = (bx * 2 + (wv & 1)) * G::kWTX + q % G::kWTX, py = (by * 2 + (wv >> 1)) * G::kWTY + q / G::kWTX;
+    active = px < W && py < H;
+    ray = (int64_t)py * W + px;
+    if (active) {
+      camera_ray(A.cam.c2w, A.cam.fx, A.cam.fy, W, H, px, py, origin, dir);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) vdir[a] = dir[a];
+    }
+  } else {
+    ray = blockIdx.x * (int64_t)kRaysPerBlock + row;
+    active = ray < A.B;
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        origin[a] = A.origins[ray * 3 + a];
+        dir[a] = A.dirs[ray * 3 + a];
+        vdir[a] = A.viewdirs[ray * 3 + a];
+      }
+    }
+  }
+  const int K = A.tree.basis_dim, D = A.tree.data_dim;
+  const int Kc = KF > 0 ? KF : K;
+  const float bg = A.opt.background_brightness;
+  TreeRay r;
+  to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
+  const bool alive = active && !(r.tmax < 0.0f || r.tmin > r.tmax);
+
+  if (l == 0) {
+    if (alive) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
+    else
+      for (int i = 0; i < 25; ++i) s_basis[row][i] = 0.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // march side: channel-aligned ownership (see octree_render_kernel, KF)
+  constexpr int kChM = ((KF > 0 ? KF / 4 : 6) + kRow - 1) / kRow > 0 ? ((KF > 0 ? KF / 4 : 6) + kRow - 1) / kRow : 1;
+  const int chG = Kc >> 2, chR = Kc & 3;
+  float bk[4 * kChM], bk_r = 0.0f;
+#pragma unroll
+  for (int m = 0; m < kChM; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bk[4 * m + e] = (l + kRow * m) < chG ? s_basis[row][4 * (l + kRow * m) + e] : 0.0f;
+  if (l < chR) bk_r = s_basis[row][4 * chG + l];
+  // scatter side: in deal g this lane serves ray 4 g + (lane >> 4) of the wave, data indices j, j + 16, .. of the leaf row
+  // (index-ordered, so every instruction adds 64 contiguous bytes per ray whatever K is)
+  constexpr int kSM = (3 * (KF > 0 ? KF : 25) + 15) / 16;
+  const int j = lane & 15, wave_row0 = (row / G::kRaysPerWave) * G::kRaysPerWave;
+  float sb[4][kSM];
+  int sch[kSM];
+#pragma unroll
+  for (int m = 0; m < kSM; ++m) {
+    const int idx = j + 16 * m;
+    sch[m] = idx < 3 * Kc ? idx / Kc : -1;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      sb[gq][m] = sch[m] >= 0 ? s_basis[wave_row0 + 4 * gq + (lane >> 4)][idx - sch[m] * Kc] : 0.0f;
+  }
+  const float* __restrict__ data = A.tree.data;
+  const int32_t* __restrict__ child = A.tree.child;
+
+  float g[3] = {0.f, 0.f, 0.f};
+  if (alive) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = grad_out[ray * 3 + c];
+  }
+  float accum = 0.0f;
+  int first_pass = 0;
+  if (fwd_rgb != nullptr) {                    // the caller kept the (exact) forward image: no first march
+    if (alive) accum = (g[0] * fwd_rgb[ray * 3] + g[1] * fwd_rgb[ray * 3 + 1]) + g[2] * fwd_rgb[ray * 3 + 2];
+    first_pass = 1;
+  }
+  for (int pass = first_pass; pass <= 1; ++pass) {
+    Marcher mk;
+    mk.init(s_stack[row]);
+    float t = r.tmin, light = 1.0f;
+    float out[3] = {0.f, 0.f, 0.f};
+    bool running = alive && t < r.tmax;
+    while (__builtin_amdgcn_ballot_w64(running) != 0) {
+      bool has = false;
+      int leaf_i = 0;
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, es = 0.f;
+      if (running) {
+        float pos[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + t * r.d[a]);
+        int depth;
+        const int64_t leaf = mk.find(child, pos, depth);
+        const float cube = (float)(2u << depth);
+        float local[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float p = pos[a] * cube;
+          local[a] = p - floorf(p);
+        }
+        float s0, s1;
+        dda_unit(local, r.invdir, s0, s1);
+        const float delta_t = (s1 - s0) / cube + A.opt.step_size;
+        const float* __restrict__ val = data + leaf * D;
+        const float sg = val[D - 1];
+        if (sg > A.opt.sigma_thresh) {
+          const float dtw = delta_t * r.delta_scale;
+          const float att = expf(-dtw * sg);
+          const float weight = light * (1.0f - att);
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+          for (int m = 0; m < kChM; ++m) {
+            const int gi = l + kRow * m;
+            if (gi < chG) {
+              const f32x4u c0 = *reinterpret_cast<const f32x4u*>(val + 4 * gi);
+              const f32x4u c1 = *reinterpret_cast<const f32x4u*>(val + Kc + 4 * gi);
+              const f32x4u c2 = *reinterpret_cast<const f32x4u*>(val + 2 * Kc + 4 * gi);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                p0 += c0[e] * bk[4 * m + e];
+                p1 += c1[e] * bk[4 * m + e];
+                p2 += c2[e] * bk[4 * m + e];
+              }
+            }
+          }
+          if (l < chR) {
+            const int k = 4 * chG + l;
+            p0 += val[k] * bk_r;
+            p1 += val[Kc + k] * bk_r;
+            p2 += val[2 * Kc + k] * bk_r;
+          }
+          p0 = row_sum<kRow>(p0);
+          p1 = row_sum<kRow>(p1);
+          p2 = row_sum<kRow>(p2);
+          const float c0 = 1.0f / (1.0f + expf(-p0)), c1 = 1.0f / (1.0f + expf(-p1)), c2 = 1.0f / (1.0f + expf(-p2));
+          if (pass == 0) {
+            out[0] += weight * c0;
+            out[1] += weight * c1;
+            out[2] += weight * c2;
+            light = light * att;
+          } else {
+            const float total = (g[0] * c0 + g[1] * c1) + g[2] * c2;
+            e0 = weight * g[0] * c0 * (1.0f - c0);
+            e1 = weight * g[1] * c1 * (1.0f - c1);
+            e2 = weight * g[2] * c2 * (1.0f - c2);
+            light = light * att;
+            accum -= weight * total;
+            es = dtw * (total * light - accum);
+            leaf_i = (int)leaf;                    // n_internal < 2^28: node * 8 + cell fits 31 bits
+            has = true;
+          }
+        }
+        const float tn = t + delta_t;
+        running = tn > t && tn < r.tmax;           // !(tn > t): step below the resolution of t, stop rather than spin
+        t = tn;
+      }
+      if (pass == 1) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int src = 4 * (4 * gq + (lane >> 4));            // first lane of the served ray's row
+          const int h = __shfl((int)has, src);
+          if (__builtin_amdgcn_ballot_w64(h != 0) == 0) continue;   // no sample in this deal (wave-uniform)
+          const int lf = __shfl(leaf_i, src);
+          const float q0 = __shfl(e0, src), q1 = __shfl(e1, src), q2 = __shfl(e2, src), qs = __shfl(es, src);
+          if (h) {
+            float* __restrict__ gv = grad_data + (int64_t)lf * D;
+#pragma unroll
+            for (int m = 0; m < kSM; ++m)
+              if (sch[m] >= 0)
+                unsafeAtomicAdd(gv + j + 16 * m, sb[gq][m] * (sch[m] == 0 ? q0 : (sch[m] == 1 ? q1 : q2)));
+            if (j == 0) unsafeAtomicAdd(gv + D - 1, qs);
+          }
+        }
+      }
+    }
+    if (pass == 0) accum = (g[0] * (out[0] + light * bg) + g[1] * (out[1] + light * bg)) + g[2] * (out[2] + light * bg);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // image loss and SGD
 // ------------------------------------------------------------------------------------------
@@ -1000,7 +1199,9 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // moves to fewer lanes: forward 3.51 / 2.98 / 2.44 ms for 16 / 8 / 4 lanes (dword loads: 3.88 / 3.11 / 4.23), SH25 3.45 /
 // 3.06 ms for 8 / 4, SH9 2.14 ms at 4; 2 lanes measured slower again (3.25 ms).  At 4 lanes the channel-aligned ownership
 // with compile-time K (KF) then takes SH16 to 1.61 ms, SH25 to 2.35 ms, SH9 to 1.75 ms.
-// So: forward 4 lanes, backward 16.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+// Backward at "4 lanes" is octree_render_bwd4_kernel (4-lane march, 16-lane cooperative scatter): 10.47 ms reusing the
+// forward image / 11.20 ms without, against 10.86 / 11.90 ms for the 16-lane kernel (SH25: 14.46 / 15.49 against 14.87 / 16.02).
+// So: 4 lanes both ways.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
 static int g_row_override[2] = {0, 0};   // [forward, backward]; 0 = the measured default
 static int render_row(bool backward, int data_dim) {
   static const int forced = [] {
@@ -1011,7 +1212,7 @@ static int render_row(bool backward, int data_dim) {
   if (g_row_override[backward ? 1 : 0]) return g_row_override[backward ? 1 : 0];
   if (forced) return forced;
   (void)data_dim;
-  return backward ? 16 : 4;
+  return 4;
 }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
@@ -1103,7 +1304,19 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
               "pxo_octree_render_bwd: out_rgb must come from an exact march (stop_thresh == 0), got stop_thresh %g",
               (double)opts->stop_thresh);
   switch (row) {
-    case 4: hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
+    case 4:
+#if PXO_OCT_BWD4
+#define PXO_BWD4(KF_) hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, grad_out, grad_data)
+      switch (tree->basis_dim) {
+        case 16: PXO_BWD4(16); break;
+        case 25: PXO_BWD4(25); break;
+        default: PXO_BWD4(-1); break;
+      }
+#undef PXO_BWD4
+#else
+      hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data);
+#endif
+      break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
     default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
   }

@@ -148,7 +148,7 @@ def _camera(c2w, width, height, fx, fy):
 
 
 def set_lanes_per_ray(forward=0, backward=0):
-    """Lanes per ray of the renderer launches (4 / 8 / 16; 0 = measured default 4 forward, 16 backward)."""
+    """Lanes per ray of the renderer launches (4 / 8 / 16; 0 = measured default 4)."""
     check(_lib.load().pxo_octree_set_lanes_per_ray(int(forward), int(backward)), "pxo_octree_set_lanes_per_ray")
 
 

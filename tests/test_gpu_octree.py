@@ -239,7 +239,7 @@ def test_octree_render_gradient_matches_oracle(K):
 
 @pytest.mark.parametrize("lanes", [4, 8, 16])
 def test_octree_render_every_lanes_per_ray_template(lanes):
-    """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 4 forward / 16 backward);
+    """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 4: backward = 4-lane march + 16-lane cooperative scatter);
     every instantiation is held to the same oracle bounds, forward and gradient, for every SH format."""
     oops = _oops(); dev = _gpu()
     try:

@@ -505,3 +505,42 @@ def test_octree_full_size_properties():
     # a pixel that misses the volume gets no gradient and the background colour
     miss = ~seen
     assert bool(miss.any()) and float((im[miss] - 1.0).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("K", [16, 25])
+def test_render_kernel_variants_agree_at_image_size(K):
+    """The lane-count variants are different kernels (forward: channel-aligned 16-byte reads at 4 lanes, index-ordered at
+    8 / 16; backward: 4-lane march + 16-lane cooperative scatter against the plain 8- / 16-lane kernels).  The oracle
+    comparisons above hold each of them on a handful of rays; here they are held against each other on a 401 x 397 image
+    (ragged patches on both borders) of a depth-6 tree: images to the oracle tolerance, gradients (float atomics: the order
+    of the adds is not fixed) to 1e-5 relative, repeat launches of the forward bit-identical, and the gradient launch
+    that re-marches for the colour equal to the one that is handed the forward image."""
+    oops = _oops(); dev = _gpu()
+    t = _random_tree(6, 900 + K, K, p=0.05)
+    view, (child, data) = _device_tree(t, dev)
+    W, H, fx = 401, 397, 420.0
+    c2w = torch.from_numpy(_pose(40.0, 25.0)).to(dev)
+    opt = oops.render_opts(1e-3)
+    gout = torch.randn(H, W, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(K))
+    imgs, grads = {}, {}
+    try:
+        for lanes in (4, 8, 16):
+            oops.set_lanes_per_ray(lanes, lanes)
+            imgs[lanes] = oops.octree_render_persp(view, c2w, W, H, fx, opt)
+            assert torch.equal(imgs[lanes], oops.octree_render_persp(view, c2w, W, H, fx, opt))
+            g = torch.zeros_like(data)
+            oops.octree_render_persp_bwd(view, c2w, W, H, fx, opt, gout, g, out_rgb=imgs[lanes])
+            grads[lanes] = g
+        g2 = torch.zeros_like(data)
+        oops.set_lanes_per_ray(4, 4)
+        oops.octree_render_persp_bwd(view, c2w, W, H, fx, opt, gout, g2)          # two marches, no forward image
+    finally:
+        oops.set_lanes_per_ray(0, 0)
+    assert float(imgs[16].std()) > 0.05                                              # a real image, not background
+    for lanes in (4, 8):
+        close(f"SH{K} image {lanes} vs 16 lanes", imgs[lanes], imgs[16], rtol=0, atol=2e-5)
+        rel = float((grads[lanes].double() - grads[16].double()).norm() / grads[16].double().norm())
+        assert rel < 1e-5, (lanes, rel)
+    assert float(grads[16].abs().max()) > 0
+    rel = float((g2.double() - grads[4].double()).norm() / grads[4].double().norm())
+    assert rel < 1e-5, rel

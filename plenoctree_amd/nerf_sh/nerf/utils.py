@@ -85,6 +85,13 @@ def define_flags(parser=None):
     a("--chunk", type=int, default=8192)
     a("--approx_eval_skip", type=int, default=1)     # evaluate only every x images (utils.py:225-229)
     a("--seed", type=int, default=20200823)
+    # reference flags of parts that are not built here (LLFF scenes, the view-conditioned vanilla-NeRF head): accepted with
+    # the reference's defaults so that its command lines and presets parse; check_supported rejects what would use them
+    a("--spherify", type=_bool, default=False)             # utils.py:89
+    a("--render_path", type=_bool, default=False)          # :90-94
+    a("--llffhold", type=int, default=8)                   # :95-100
+    a("--net_depth_condition", type=int, default=1)        # :108
+    a("--net_width_condition", type=int, default=128)      # :109
     return p
 
 
@@ -131,6 +138,8 @@ def check_supported(args):
         bad.append("min/max_deg_point != 0/10")
     if args.noise_std is not None:
         bad.append("noise_std")
+    if getattr(args, "render_path", False) or getattr(args, "spherify", False):
+        bad.append("render_path / spherify (LLFF scenes)")
     if args.legacy_posenc_order:
         bad.append("legacy_posenc_order")
     if (args.net_activation.lower(), args.rgb_activation.lower(), args.sigma_activation.lower()) != ("relu", "sigmoid", "relu"):

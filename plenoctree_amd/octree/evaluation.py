@@ -19,6 +19,7 @@ def define_flags():
     p = utils.define_flags()
     a = p.add_argument
     a("--input", type=str, default="./tree_opt.npz")            # octree/evaluation.py:54-58
+    a("--write_vid", type=str, default=None)                     # :59-63 (mp4 through imageio there; GIF through PIL here)
     a("--write_images", type=str, default=None)                  # :64-68
     a("--renderer_step_size", type=float, default=1e-4)          # octree/nerf/utils.py:211-215
     a("--no_early_stop", action="store_true")
@@ -37,10 +38,17 @@ def main(argv=None):
     if comm.rank == 0:
         print("N3Tree load", args.input, flush=True)
     tree = N3Tree.load(args.input, map_location=device)
-    psnr, ssim, frames = extraction.eval_octree(tree, dataset, args, comm, want_frames=args.write_images is not None,
-                                                want_ssim=True)
+    want_frames = args.write_images is not None or args.write_vid is not None
+    psnr, ssim, frames = extraction.eval_octree(tree, dataset, args, comm, want_frames=want_frames, want_ssim=True)
     if comm.rank == 0:
         print("Average PSNR", psnr, "SSIM", ssim, flush=True)
+    if args.write_vid is not None and frames:
+        # imageio / ffmpeg are not installed: this rank's frames as an animated GIF at the requested path's stem
+        from PIL import Image
+        path = os.path.splitext(args.write_vid)[0] + (".gif" if comm.world == 1 else f".rank{comm.rank}.gif")
+        print("Writing to", path, flush=True)
+        ims = [Image.fromarray((im.numpy() * 255).astype(np.uint8)) for _, im in frames]
+        ims[0].save(path, save_all=True, append_images=ims[1:], duration=50, loop=0)
     if args.write_images is not None:
         from PIL import Image
         os.makedirs(args.write_images, exist_ok=True)

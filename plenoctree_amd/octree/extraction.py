@@ -55,13 +55,14 @@ def grid_sigma(model, state, reso, center, radius, comm=None):
     return torch.cat(parts)
 
 
-def auto_scale(model, state, center, radius, init_grid_depth=8, scale_alpha_thresh=0.01, comm=None):
+def auto_scale(model, state, center, radius, init_grid_depth=8, scale_alpha_thresh=0.01, comm=None, z_min=None,
+               z_max=None):
     """Bounding box of sigma >= thresh on a 2^depth grid (extraction.py:244-286)."""
     reso = 2 ** init_grid_depth
     sig = grid_sigma(model, state, reso, center, radius, comm)
     sigma_thresh = -np.log(1.0 - scale_alpha_thresh) / (2.0 / reso)
     offset, scale = tree_transform(center, radius)
-    mask = (sig >= sigma_thresh).reshape(reso, reso, reso)
+    mask = z_range_mask((sig >= sigma_thresh), reso, offset, scale, z_min, z_max).reshape(reso, reso, reso)
     arr = (torch.arange(reso, dtype=torch.float32, device=sig.device) + 0.5) / reso
     lc, uc = [], []
     for ax in range(3):
@@ -95,6 +96,23 @@ def calculate_grid_weights(dataset, sigmas, reso, invradius, offset, step_size, 
     return comm.all_reduce_max(weight)
 
 
+def z_range_mask(mask, reso, offset, scale, z_min, z_max):
+    """The reference drops grid planes with world z outside [z_min, z_max] before it builds the point list
+    (:257-260, :298-301; NDC scenes); on the dense mask (x slowest, z fastest) that is clearing those planes."""
+    if z_min is None and z_max is None:
+        return mask
+    arr = (torch.arange(reso, dtype=torch.float32, device=mask.device) + 0.5) / reso
+    zz = (arr - float(offset[2])) / float(scale[2])
+    keep = torch.ones(reso, dtype=torch.bool, device=mask.device)
+    if z_min is not None:
+        keep &= zz >= z_min
+    if z_max is not None:
+        keep &= zz <= z_max
+    m = mask.view(reso, reso, reso)
+    m &= keep.to(m.dtype).view(1, 1, reso) if m.dtype != torch.bool else keep.view(1, 1, reso)
+    return mask
+
+
 def step1(args, tree, model, state, dataset, comm):
     """Grid evaluation, masking and tree build (:288-352)."""
     reso = 2 ** (args.init_grid_depth + 1)
@@ -110,6 +128,8 @@ def step1(args, tree, model, state, dataset, comm):
     else:
         raise ValueError(args.masking_mode)
     del sig
+    offset, scale = tree_transform(center, radius)
+    mask = z_range_mask(mask, reso, offset, scale, getattr(args, "z_min", None), getattr(args, "z_max", None))
     tree.refine_from_mask(mask)
     if tree.max_depth != args.init_grid_depth:
         raise RuntimeError(f"empty mask: the tree has depth {tree.max_depth}, expected {args.init_grid_depth} "
@@ -196,6 +216,11 @@ def define_flags():
     a("--scale_alpha_thresh", type=float, default=0.01)
     a("--tree_branch_n", type=int, default=2)
     a("--eval", type=utils._bool, default=True)
+    a("--max_refine_prop", type=float, default=0.5)          # defined by the reference (:86-90), read nowhere
+    a("--z_min", type=float, default=None)                   # :91-100: keep only grid points with z_min <= z <= z_max
+    a("--z_max", type=float, default=None)
+    a("--is_jaxnerf_ckpt", type=utils._bool, nargs="?", const=True, default=False)   # :117-121; see main()
+    a("--projection_samples", type=int, default=10000)       # :133-137: SH projection of a view-dependent NeRF only
     a("--renderer_step_size", type=float, default=1e-4)
     a("--no_early_stop", action="store_true")
     return p
@@ -212,6 +237,9 @@ def main(argv=None):
     utils.check_flags(args, require_data=True, world_size=comm.world)
     say = print if comm.rank == 0 else (lambda *a, **k: None)
     say("* Loading NeRF", flush=True)
+    # --is_jaxnerf_ckpt (:117-121, octree/nerf/models.py:45): the reference reads either a flax-msgpack checkpoint of
+    # nerf_sh.train or a torch state dict; this path always reads the former (what nerf_sh.train here and the reference's
+    # JAX trainer both write), so the flag is accepted and changes nothing.
     model, state = models.get_model_state(args, device, restore=True)
     dataset = datasets.get_dataset("train", args, device)
     if args.bbox_from_data:                                  # :447-451 (NSVF datasets carry bbox.txt)
@@ -225,7 +253,8 @@ def main(argv=None):
         center, radius = _floats(args.center, "center"), _floats(args.radius, "radius")
     if args.autoscale:
         say("* Step 0: Auto scale", flush=True)
-        center, radius = auto_scale(model, state, center, radius, args.init_grid_depth, args.scale_alpha_thresh, comm)
+        center, radius = auto_scale(model, state, center, radius, args.init_grid_depth, args.scale_alpha_thresh, comm,
+                                    args.z_min, args.z_max)
         say("Autoscale result center", center, "radius", radius, flush=True)
     radius = [r * args.bbox_scale for r in radius]
     if args.bbox_cube:

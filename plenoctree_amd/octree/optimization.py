@@ -11,6 +11,7 @@ mini-batch at the same lr: N times smaller effective updates per epoch).  Adam i
 
     python -m plenoctree_amd.octree.optimization --input tree.npz --output tree_opt.npz --config blender --data_dir ...
 """
+import os
 import sys
 
 import numpy as np
@@ -28,6 +29,7 @@ def define_flags():
     a = p.add_argument
     a("--input", type=str, default="./tree.npz")
     a("--output", type=str, default="./tree_opt.npz")
+    a("--render_interval", type=int, default=0)               # :71-74: every n-th validation image is also written out
     a("--val_interval", type=int, default=2)
     a("--num_epochs", type=int, default=80)
     a("--sgd", type=utils._bool, default=True)
@@ -36,6 +38,7 @@ def define_flags():
     a("--sgd_nesterov", type=utils._bool, default=False)
     a("--split_train", type=utils._bool, default=None)
     a("--split_holdout_prop", type=float, default=0.2)
+    a("--write_vid", type=str, default=None)                  # octree/optimization.py:99-103: defined there, read nowhere
     a("--nosave", action="store_true")
     a("--continue_on_decrease", action="store_true")
     a("--renderer_step_size", type=float, default=1e-4)
@@ -79,10 +82,16 @@ def train_image(renderer, opt, c2w, gt, H, W, focal):
 
 
 @torch.no_grad()
-def run_validation(renderer, c2ws, images, H, W, focal, comm):
+def run_validation(renderer, c2ws, images, H, W, focal, comm, vis=None):
+    """run_test_step (:189-208).  vis = (directory, step index, interval): every interval-th image is written as
+    `<dir>/<step>_<j>.png`, ground truth and render side by side (:202-205)."""
     acc = torch.zeros(2, dtype=torch.float64, device=renderer.tree.device)
     for j in range(comm.rank, len(c2ws), comm.world):
         im = renderer.render_persp(c2ws[j], width=W, height=H, fx=focal, fast=False)
+        if vis is not None and vis[2] > 0 and j % vis[2] == 0:
+            from PIL import Image
+            pair = torch.cat((images[j], im.clamp(0.0, 1.0)), dim=1)
+            Image.fromarray((pair * 255).to(torch.uint8).cpu().numpy()).save(os.path.join(vis[0], f"{vis[1]:04}_{j:04}.png"))
         sse, _ = oops.image_mse(im, images[j], want_grad=False)
         acc[0] += -10.0 * torch.log10(sse.double().reshape(()) / im.numel())    # on the device: no host sync per image
         acc[1] += 1
@@ -99,7 +108,12 @@ def fit(args, tree, train, val, H, W, focal, comm, say=print):
     renderer = VolumeRenderer(tree, step_size=args.renderer_step_size)
     opt = TreeOptimizer(tree, args)
     say("Using SGD, lr" if args.sgd else "Using Adam, lr", args.lr, flush=True)
-    best = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
+    vis_dir = None
+    if getattr(args, "render_interval", 0) > 0:
+        vis_dir = os.path.splitext(args.input)[0] + "_render"                    # :163-164
+        os.makedirs(vis_dir, exist_ok=True)
+    vis = lambda step: None if vis_dir is None else (vis_dir, step, args.render_interval)
+    best = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm, vis(0))
     say("** initial val psnr ", best, flush=True)
     history, best_tree = [(0, None, best)], None
     n_train = len(train_gt)
@@ -118,7 +132,7 @@ def fit(args, tree, train, val, H, W, focal, comm, say=print):
         train_psnr = float(tpsnr) / n_train
         say("epoch", epoch, "** train_psnr", train_psnr, flush=True)
         if epoch % args.val_interval == args.val_interval - 1 or epoch == args.num_epochs - 1:
-            val_psnr = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm)
+            val_psnr = run_validation(renderer, test_c2w, test_gt, H, W, focal, comm, vis(epoch + 1))
             say("** val psnr ", val_psnr, "best", best, flush=True)
             history.append((epoch + 1, train_psnr, val_psnr))
             if val_psnr > best:

@@ -171,3 +171,43 @@ def test_bench_self_launch_command():
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
         assert r.returncode != 0 and "only 0 ROCm device(s) visible" in (r.stderr + r.stdout)
+
+
+def test_every_reference_flag_parses():
+    """A command line written for the reference must parse here: every flag the reference's entry points define
+    (absl `flags.DEFINE_*` in nerf_sh/nerf/utils.py, octree/nerf/utils.py and the drivers) exists in the matching parser.
+    The list is the reference's own, frozen here (the reference tree is not available on the GPU box)."""
+    from plenoctree_amd.nerf_sh import train, eval as eval_mod, gen_video, gen_mesh
+    from plenoctree_amd.nerf_sh.nerf import utils
+    from plenoctree_amd.octree import extraction, optimization, evaluation
+    common = ["train_dir", "data_dir", "config", "dataset", "image_batching", "white_bkgd", "batch_size", "factor", "spherify",
+              "render_path", "llffhold", "model", "near", "far", "net_depth", "net_width", "net_depth_condition",
+              "net_width_condition", "weight_decay_mult", "skip_layer", "num_rgb_channels", "num_sigma_channels", "randomized",
+              "min_deg_point", "max_deg_point", "deg_view", "num_coarse_samples", "num_fine_samples", "use_viewdirs", "sh_deg",
+              "sg_dim", "noise_std", "lindisp", "net_activation", "rgb_activation", "sigma_activation", "legacy_posenc_order",
+              "lr_init", "lr_final", "lr_delay_steps", "lr_delay_mult", "max_steps", "save_every", "print_every",
+              "render_every", "gc_every", "sparsity_weight", "sparsity_length", "sparsity_radius", "sparsity_npoints",
+              "eval_once", "save_output", "chunk", "approx_eval_skip"]
+    per_driver = {
+        extraction: ["output", "center", "radius", "alpha_thresh", "max_refine_prop", "z_min", "z_max", "tree_branch_n",
+                     "init_grid_depth", "samples_per_cell", "is_jaxnerf_ckpt", "masking_mode", "weight_thresh",
+                     "projection_samples", "bbox_from_data", "data_bbox_scale", "autoscale", "bbox_cube", "bbox_scale",
+                     "scale_alpha_thresh", "eval", "renderer_step_size", "no_early_stop"],
+        optimization: ["input", "output", "render_interval", "val_interval", "num_epochs", "sgd", "lr", "sgd_momentum",
+                       "sgd_nesterov", "write_vid", "split_train", "split_holdout_prop", "nosave", "continue_on_decrease",
+                       "renderer_step_size", "no_early_stop"],
+        evaluation: ["input", "write_vid", "write_images", "renderer_step_size", "no_early_stop"],
+        gen_video: ["elevation", "num_views", "height", "width", "camera_angle_x", "intrin", "radius", "fps", "up_axis",
+                    "write_poses"],
+        gen_mesh: ["reso", "c1", "c2", "iso", "coarse", "point_chunk"],
+    }
+    def dests(parser):
+        return {a.dest for a in parser._actions}
+    base = dests(utils.define_flags())
+    missing = [f for f in common if f not in base]
+    assert not missing, missing
+    for mod, names in per_driver.items():
+        have = dests(mod.define_flags())
+        missing = [f for f in names + common if f not in have]
+        assert not missing, (mod.__name__, missing)
+    assert hasattr(train, "main") and hasattr(eval_mod, "main")

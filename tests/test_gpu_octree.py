@@ -440,14 +440,31 @@ def test_extraction_pipeline_end_to_end(tmp_path):
     # the saved file loads and renders; early-stop and exact renders agree to the thresholds
     loaded = svox.N3Tree.load(out, map_location=dev)
     assert loaded.n_internal == tree.n_internal and torch.equal(loaded.child, tree.child)
-    psnr = evaluation.main(common + ["--input", out, "--renderer_step_size", "1e-3", "--approx_eval_skip", "1"])
-    assert np.isfinite(psnr)
+    vid = os.path.join(str(tmp_path), "eval.mp4")
+    psnr = evaluation.main(common + ["--input", out, "--renderer_step_size", "1e-3", "--approx_eval_skip", "1",
+                                     "--write_vid", vid])
+    assert np.isfinite(psnr) and os.path.exists(os.path.splitext(vid)[0] + ".gif")
+    # --z_min / --z_max (extraction.py:91-100, :298-301): grid planes outside the world-z range never enter the tree, the
+    # rest of the mask is untouched; the reference's command line spelling (--is_jaxnerf_ckpt etc.) parses
+    tz = extraction.main(common + ["--output", os.path.join(str(tmp_path), "tree_z.npz"), "--init_grid_depth", "4",
+                                   "--masking_mode", "sigma", "--samples_per_cell", "8", "--eval", "false", "--z_max", "0.2",
+                                   "--z_min", "-0.9", "--is_jaxnerf_ckpt", "--max_refine_prop", "0.5",
+                                   "--projection_samples", "10000"])
+    reso = 32
+    grid = (torch.stack(torch.meshgrid(*[(torch.arange(reso, device=dev) + 0.5) / reso] * 3, indexing="ij"), -1).reshape(-1, 3)
+            - 0.5) * 3.0
+    leaves = oops.tree_query(tz.child, grid, tz.offset, tz.invradius)
+    depth_of = tz.parent_depth[leaves // 8, 1].view(reso, reso, reso)
+    zw = ((torch.arange(reso, device=dev) + 0.5) / reso - 0.5) * 3.0
+    outside = (zw > 0.2) | (zw < -0.9)
+    assert int((depth_of[:, :, outside] == 4).sum()) == 0 and int((depth_of[:, :, ~outside] == 4).sum()) > 0
     # a few optimisation epochs on 50x50 images improve the training PSNR
     hist = optimization.main(common + ["--input", out, "--output", os.path.join(str(tmp_path), "tree_opt.npz"),
                                        "--num_epochs", "3", "--val_interval", "1", "--renderer_step_size", "1e-3",
-                                       "--lr", "2e4", "--continue_on_decrease"])
+                                       "--lr", "2e4", "--continue_on_decrease", "--render_interval", "100"])
     train_psnrs = [h[1] for h in hist if h[1] is not None]
     assert len(train_psnrs) == 3 and train_psnrs[-1] > train_psnrs[0], hist
+    assert os.path.exists(os.path.join(os.path.splitext(out)[0] + "_render", "0000_0000.png"))    # optimization.py:163,205
 
 
 def test_octree_full_size_properties():

@@ -435,11 +435,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // the skinny products (enc-based pair, heads): two workgroups per CU (256 / 128 ranges measured equal or slower at
   // 4096, 1024 and 512 rays per step)
   int64_t rpw2; int P2;
-  {
-    static const int ranges2_override = getenv("PXO_WGRAD_RANGES2") ? atoi(getenv("PXO_WGRAD_RANGES2")) : 0;   // A/B hook
-    split_rows(M, ranges2_override > 0 && ranges2_override <= 2 * num_cus() ? ranges2_override : 2 * (int64_t)num_cus(),
-               &rpw2, &P2);
-  }
+  split_rows(M, 2 * (int64_t)num_cus(), &rpw2, &P2);
   const float* h7 = acts + (int64_t)7 * MW;
   auto head = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);

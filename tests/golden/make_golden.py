@@ -8,6 +8,7 @@ jax/flax/absl/svox):
   octree/nerf/model_utils.py  (MLP, posenc)
   octree/nerf/models.py       (NerfModel.eval_points_raw)
   nerf_sh/nerf/sh.py          (eval_sh)
+  octree/nerf/sh_proj.py      (EvalSH: the reference's second, independent real-SH evaluation)
 and, with stub modules standing in for `absl.flags` and `cv2` (flag registration / resize only, no arithmetic):
   octree/nerf/utils.py        (generate_rays, compute_psnr)
   octree/nerf/datasets.py     (Blender and NSVF loaders, run on the tiny on-disk scenes of golden_scenes.py)
@@ -335,6 +336,15 @@ def main():
     rays = ref_jutils.generate_rays(9, 7, 12.5, c2w)
     out["rays_origins"], out["rays_directions"], out["rays_viewdirs"] = [np.asarray(r, f32) for r in rays]
     np.savez(os.path.join(HERE, "nerf_sh_utils.npz"), **out)
+
+    # ---- the reference's SECOND real-SH implementation: octree/nerf/sh_proj.py EvalSH(l, m, dirs) (:56-239) -----
+    # (own generator: the draws above must not move)
+    ref_proj = _load("ref_sh_proj", os.path.join(REF, "octree/nerf/sh_proj.py"))
+    rng2 = np.random.default_rng(20200823)
+    d = rng2.normal(size=(64, 3))
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float64)
+    basis = np.stack([np.asarray(ref_proj.EvalSH(l, m, torch.tensor(d))) for l in range(5) for m in range(-l, l + 1)], -1)
+    np.savez(os.path.join(HERE, "sh_proj.npz"), dirs=d, basis=basis)
     print("golden vectors written to", HERE)
 
 

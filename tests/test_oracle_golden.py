@@ -202,3 +202,24 @@ def test_host_helpers_match_the_reference_utils(golden_dir):
     np.testing.assert_allclose(rays.directions, g["rays_directions"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(rays.viewdirs, g["rays_viewdirs"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(rays.origins, g["rays_origins"], rtol=0, atol=0)
+
+
+def test_sh_basis_against_the_references_second_sh_implementation(golden_dir):
+    """octree/nerf/sh_proj.py:56-239 (EvalSH, the hard-coded real SH the reference uses to project view-dependent
+    NeRFs) is an implementation independent of nerf_sh/nerf/sh.py's eval_sh; the two oracles' basis functions must
+    equal it band by band, index l (l + 1) + m, signs included."""
+    g = np.load(os.path.join(golden_dir, "sh_proj.npz"))
+    dirs = torch.tensor(g["dirs"])                                   # float64 unit vectors
+    assert g["basis"].shape == (64, 25)
+    ours = O.sh_basis(4, dirs).numpy()
+    np.testing.assert_allclose(ours, g["basis"], rtol=0, atol=2e-7)  # the constants of sh.py are float32 literals
+    for deg in range(4):                                             # lower degrees are prefixes of the same list
+        K = (deg + 1) ** 2
+        np.testing.assert_allclose(O.sh_basis(deg, dirs).numpy(), g["basis"][:, :K], rtol=0, atol=2e-7)
+    # eval_sh is the contraction with that basis
+    sh = torch.randn(64, 3, 25, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    np.testing.assert_allclose(O.eval_sh(4, sh, dirs).numpy(), np.einsum("nck,nk->nc", sh.numpy(), g["basis"]),
+                               rtol=0, atol=2e-6)
+    from oracle import octree_oracle as T                            # the octree oracle's per-ray basis (float32)
+    for i in range(0, 64, 7):
+        np.testing.assert_allclose(T.sh_basis_np(25, g["dirs"][i]).astype(np.float64), g["basis"][i], rtol=0, atol=2e-6)

@@ -604,9 +604,13 @@ def test_cli_train_eval_extraction(tmp_path):
     psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0
     # the same evaluation with the opt-in split-precision MLP forward: the same PSNR to well inside 1e-3 dB
-    psnrs_x3 = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false",
+    psnrs_x3 = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "true",
                                         "--mlp_precision", "bf16x3"])
     assert max(abs(a - b) for a, b in zip(psnrs, psnrs_x3)) < 1e-3, (psnrs, psnrs_x3)
+    preds = os.path.join(str(tmp_path), "test_preds")                    # nerf_sh/eval.py:64-66,107-129
+    for name in ("000.png", "disp_000.png", "100.png", "disp_100.png", "psnr.txt", "ssim.txt", "psnrs_60.txt", "ssims_60.txt"):
+        assert os.path.exists(os.path.join(preds, name)), name
+    assert abs(float(open(os.path.join(preds, "psnr.txt")).read()) - np.mean(psnrs_x3)) < 1e-6
     with pytest.raises(ValueError, match="inference option"):
         train.main(common + ["--mlp_precision", "bf16x3"])
     from plenoctree_amd.nerf_sh import gen_video

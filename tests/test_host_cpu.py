@@ -211,3 +211,18 @@ def test_every_reference_flag_parses():
         missing = [f for f in names + common if f not in have]
         assert not missing, (mod.__name__, missing)
     assert hasattr(train, "main") and hasattr(eval_mod, "main")
+
+
+def test_eval_output_files(tmp_path):
+    """nerf_sh/eval.py:107-129: file names and contents of what the evaluation leaves in <train_dir>/test_preds."""
+    from PIL import Image
+    from plenoctree_amd.nerf_sh import eval as eval_mod
+    rgb = torch.rand(5, 7, 3) * 1.4 - 0.2                      # values outside [0, 1] are clipped (utils.py:469-480)
+    disp = torch.rand(5, 7)
+    eval_mod.save_outputs(str(tmp_path), 3, rgb, disp)
+    im = np.asarray(Image.open(tmp_path / "003.png"))
+    assert im.shape == (5, 7, 3) and np.array_equal(im, (np.clip(rgb.numpy(), 0.0, 1.0) * 255.0).astype(np.uint8))
+    dm = np.asarray(Image.open(tmp_path / "disp_003.png"))
+    assert dm.shape == (5, 7) and np.array_equal(dm, (disp.numpy() * 255.0).astype(np.uint8))
+    eval_mod.save_summary(str(tmp_path), 1234, [20.0, 30.0], [0.5, 0.75])
+    assert float(open(tmp_path / "psnr.txt").read()) == 25.0 and open(tmp_path / "ssims_1234.txt").read() == "0.5 0.75"

@@ -382,7 +382,7 @@ class N3Tree:
         dev = torch.device(map_location if map_location is not None else device)
         z = np.load(path)
         if "quant_colors" in z.files:
-            raise NotImplementedError("median-cut compressed trees (octree/compression.py) are not supported")
+            z = _dequantized(z)
         t = object.__new__(cls)
         t.N = 2
         fmt = str(z["data_format"]) if "data_format" in z.files else "RGBA"
@@ -412,6 +412,30 @@ class N3Tree:
         if t.max_depth > TREE_MAX_DEPTH:
             raise NotImplementedError(f"tree depth {t.max_depth} exceeds {TREE_MAX_DEPTH}")
         return t
+
+
+def _dequantized(z):
+    """Undoes octree/compression.py:88-136 on a loaded npz: `data` [n,2,2,2,3K+1] from `quant_colors` [K', 2^bits, 3] +
+    `quant_map` [K', n,2,2,2] (+ `data_retained` [r, n,2,2,2,3] for the first r basis functions) + `sigma` [n,2,2,2]."""
+    out = {k: z[k] for k in z.files}
+    colors, qmap, sigma = z["quant_colors"].astype(np.float32), z["quant_map"].astype(np.int64), z["sigma"].astype(np.float32)
+    retained = z["data_retained"].astype(np.float32) if "data_retained" in z.files else np.zeros((0,) + sigma.shape + (3,), np.float32)
+    K = retained.shape[0] + colors.shape[0]
+    rgb = np.empty(sigma.shape + (3, K), np.float32)                      # [..., channel, basis]: the layout of `data`
+    for b in range(retained.shape[0]):
+        rgb[..., b] = retained[b]
+    for b in range(colors.shape[0]):
+        rgb[..., retained.shape[0] + b] = colors[b][qmap[b]]
+    out["data"] = np.concatenate([rgb.reshape(sigma.shape + (3 * K,)), sigma[..., None]], -1)
+    return _NpzDict(out)
+
+
+class _NpzDict(dict):
+    """dict with the `.files` attribute of an NpzFile."""
+
+    @property
+    def files(self):
+        return list(self.keys())
 
 
 def parent_depth_from_child(child):
@@ -516,8 +540,63 @@ def _grid_weight_render(grid_data, cam, opts, offset, invradius):
     return w, w > 0
 
 
-def _quantize_median_cut(*a, **k):
-    raise NotImplementedError("quantize_median_cut (octree/compression.py) is not part of the MI355X path")
+def _quantize_median_cut(data, weights, order):
+    """_C.quantize_median_cut(data [n,3], weights [n] or empty, order) -> (colors [2^order, 3] float32, color_id_map [n]
+    int32), as called by octree/compression.py:114-116.
+
+    Median cut (Heckbert): `order` rounds, every box split at its (weighted) median along the axis of its largest extent,
+    lower half first, so box b of a round becomes boxes 2b and 2b+1 of the next; a colour is the (weighted) mean of its
+    box, a point's id the index of its box.  All boxes of a round are split at once (two stable sorts per round), in
+    torch on whatever device `data` lives on.  svox's native implementation is not in the reference tree: this follows
+    the published algorithm and the call site's contract (shapes, dtypes, id range), not svox's tie-breaking - parity
+    unpinned, like the rest of the svox surface.  Boxes that run empty (n < 2^order) get colour 0."""
+    x = torch.as_tensor(data).detach().to(torch.float32)
+    if x.dim() != 2:
+        raise ValueError("quantize_median_cut: data must be [n, channels]")
+    n, dev = x.shape[0], x.device
+    nbox = 1 << int(order)
+    colors = torch.zeros(nbox, x.shape[1], dtype=torch.float32, device=dev)
+    if n == 0:
+        return colors, torch.zeros(0, dtype=torch.int32, device=dev)
+    w = torch.as_tensor(weights).detach().to(torch.float32).to(dev).reshape(-1)
+    weighted = w.numel() == n
+    if not weighted:
+        w = torch.ones(n, dtype=torch.float32, device=dev)
+    box = torch.zeros(n, dtype=torch.int64, device=dev)
+    for level in range(int(order)):
+        nb = 1 << level
+        lo = torch.full((nb, x.shape[1]), float("inf"), device=dev).scatter_reduce_(
+            0, box[:, None].expand_as(x), x, "amin", include_self=True)
+        hi = torch.full((nb, x.shape[1]), float("-inf"), device=dev).scatter_reduce_(
+            0, box[:, None].expand_as(x), x, "amax", include_self=True)
+        axis = (hi - lo).argmax(dim=1)                                   # per box; empty boxes give nan -> axis 0, unused
+        key = x.gather(1, axis[box][:, None])[:, 0]
+        order1 = torch.sort(key, stable=True).indices                    # by value ...
+        order2 = torch.sort(box[order1], stable=True).indices            # ... then by box, values staying sorted
+        perm = order1[order2]
+        pbox = box[perm]
+        start = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        start[1:] = torch.bincount(pbox, minlength=nb).cumsum(0)
+        rank = torch.arange(n, device=dev) - start[pbox]
+        size = (start[1:] - start[:-1])[pbox]
+        if weighted:                                                      # first point at which half of the box's weight is reached
+            cw = torch.cumsum(w[perm].double(), 0)
+            base = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), cw])[start[pbox]]
+            total = (torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), cw])[start[1:]] - \
+                     torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), cw])[start[:-1]])[pbox]
+            upper = (cw - base) > 0.5 * total
+            upper &= rank > 0                                             # never leave the lower half empty ...
+            upper |= (rank == size - 1) & (size > 1)                      # ... nor the upper one
+        else:
+            upper = rank >= size // 2                                     # nth_element at begin + size / 2
+        new_box = torch.empty_like(box)
+        new_box[perm] = 2 * pbox + upper.to(torch.int64)
+        box = new_box
+    wsum = torch.zeros(nbox, dtype=torch.float64, device=dev).index_add_(0, box, w.double())
+    acc = torch.zeros(nbox, x.shape[1], dtype=torch.float64, device=dev).index_add_(0, box, x.double() * w.double()[:, None])
+    filled = wsum > 0
+    colors[filled] = (acc[filled] / wsum[filled][:, None]).float()
+    return colors, box.to(torch.int32)
 
 
 def _get_c_extension():

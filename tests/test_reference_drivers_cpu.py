@@ -301,6 +301,43 @@ def test_reference_extraction_steps_and_compression(ref, tmp_path, monkeypatch):
     assert torch.equal(small.data.data, back.data.data)
     z = np.load(os.path.join(out_dir, "tree.npz"))
     assert sorted(z.files) == sorted(["data_dim", "child", "invradius3", "offset", "data", "data_format"])
+    from plenoctree_amd.octree import compression as our_comp
+    assert our_comp.main([path, "--noquant", "--out_dir", str(tmp_path / "min_ours")]) and not our_comp.main(
+        [path, "--noquant", "--out_dir", str(tmp_path / "min_ours")])                       # second call: "skip"
+    zo = np.load(str(tmp_path / "min_ours" / "tree.npz"))
+    assert sorted(zo.files) == sorted(z.files) and all(np.array_equal(zo[k], z[k]) for k in z.files)
+    # ---- ... and its default mode: median-cut quantisation through _C.quantize_median_cut (:88-136), two ways:
+    # every basis function quantised, and the first one retained (--retain 1); 6 bits = 64 colours per basis function
+    for extra, tag in (([], "q"), (["--retain", "1"], "qr")):
+        qdir = str(tmp_path / tag)
+        monkeypatch.setattr(sys, "argv", ["compression.py", path, "--bits", "6", "--sigma_thresh", "0.5", "--out_dir", qdir,
+                                          "--overwrite"] + extra)
+        ref_comp.main()
+        zq = np.load(os.path.join(qdir, "tree.npz"))
+        n, kq = tree.n_internal, K - (1 if extra else 0)
+        assert zq["quant_colors"].shape == (kq, 64, 3) and zq["quant_colors"].dtype == np.float16
+        assert zq["quant_map"].shape == (kq, n, 2, 2, 2) and zq["quant_map"].dtype == np.uint16 and int(zq["quant_map"].max()) < 64
+        assert zq["sigma"].shape == (n, 2, 2, 2) and "data" not in zq.files
+        assert ("data_retained" in zq.files) == bool(extra)
+        # our loader undoes it: sigma exact below/above the threshold, colours to the quantisation error
+        q = svox.N3Tree.load(os.path.join(qdir, "tree.npz"), map_location="cpu")
+        assert torch.equal(q.child, tree.child) and q.data.shape == back.data.shape
+        sig, keep = back.data.data[..., -1], back.data.data[..., -1] > 0.5
+        assert torch.equal(q.data.data[..., -1], torch.where(keep, sig, torch.zeros_like(sig)))
+        err = (q.data.data[..., :-1] - back.data.data[..., :-1])[keep]
+        ref_spread = back.data.data[..., :-1][keep].std()
+        assert float(err.abs().mean()) < 0.5 * float(ref_spread), (float(err.abs().mean()), float(ref_spread))
+        # our own driver (plenoctree_amd.octree.compression, same flags) writes the same file
+        from plenoctree_amd.octree import compression as our_comp
+        odir = str(tmp_path / (tag + "_ours"))
+        assert our_comp.main([path, "--bits", "6", "--sigma_thresh", "0.5", "--out_dir", odir, "--overwrite"] + extra)
+        zo = np.load(os.path.join(odir, "tree.npz"))
+        assert sorted(zo.files) == sorted(zq.files)
+        for k in zq.files:
+            assert zo[k].dtype == zq[k].dtype and np.array_equal(zo[k], zq[k]), k
+        if extra:                                              # the retained basis function is kept to float16
+            d0 = back.data.data[..., :-1].reshape(n, 2, 2, 2, 3, K)[..., 0][keep]
+            assert torch.equal(q.data.data[..., :-1].reshape(n, 2, 2, 2, 3, K)[..., 0][keep], d0.half().float())
 
 
 def _small_tree_file(path, seed=3):

@@ -226,3 +226,25 @@ def test_eval_output_files(tmp_path):
     assert dm.shape == (5, 7) and np.array_equal(dm, (disp.numpy() * 255.0).astype(np.uint8))
     eval_mod.save_summary(str(tmp_path), 1234, [20.0, 30.0], [0.5, 0.75])
     assert float(open(tmp_path / "psnr.txt").read()) == 25.0 and open(tmp_path / "ssims_1234.txt").read() == "0.5 0.75"
+
+
+def test_tile_schedule_properties(tmp_path):
+    """The persistent-tile schedule of the fused MLP kernels (pxo_common.h: tile_sched - whole rounds of 128-row tiles, then
+    at most one round of 64-row half tiles) covers [0, M) exactly, never uses more than one half round, and never needs more
+    relu-mask / bias-partial slots than `mask_slots` provides: checked on the REAL header, compiled as host code
+    (tests/native/sched_check.cpp), for every M up to 5000, around every half-round boundary and at the BASELINE sizes, for
+    11 grid sizes.  A wrong schedule would silently drop or double rows for particular batch sizes only."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("needs hipcc")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sched_check")
+    cmd = [hipcc, "-O1", "-std=c++17", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "plenoctree_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "native", "sched_check.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and " bad 0 " in res.stdout, res.stdout[-2000:]
+    assert int(res.stdout.split("cases ")[1].split()[0]) > 100000

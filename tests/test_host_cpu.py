@@ -248,3 +248,27 @@ def test_tile_schedule_properties(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and " bad 0 " in res.stdout, res.stdout[-2000:]
     assert int(res.stdout.split("cases ")[1].split()[0]) > 100000
+
+
+def test_device_helpers_on_the_host(tmp_path, golden_dir):
+    """The kernels' own helper functions, compiled as host code and run on the CPU (tests/native/device_helpers_check.cpp):
+    `sh_basis<0..4>` of pxo_sh.h - the code the shading kernels and the octree renderer execute - against the reference's
+    `octree/nerf/sh_proj.py:EvalSH` vectors (tests/golden/sh_proj.npz), and the parameter-arena layout of pxo_common.h against
+    the reference's layer shapes and parameter counts."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("needs hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(golden_dir, "sh_proj.npz"))
+    raw = str(tmp_path / "sh.bin")
+    np.concatenate([g["dirs"].astype(np.float64).reshape(-1), g["basis"].astype(np.float64).reshape(-1)]).tofile(raw)
+    exe = str(tmp_path / "device_helpers_check")
+    cmd = [hipcc, "-O1", "-std=c++17", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(root, "plenoctree_amd", "csrc"), "-I" + os.path.join(root, "include"),
+           os.path.join(root, "tests", "native", "device_helpers_check.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    res = subprocess.run([exe, raw], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "dirs 64 " in res.stdout and "layout_bad 0" in res.stdout

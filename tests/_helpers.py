@@ -183,3 +183,40 @@ def oracle_loss_and_grad_given_z(flat, rays, px, cfg, z_c, z_f, sp_points, dtype
     total = total + cfg.weight_decay_mult * (sum((z ** 2).sum() for z in leaves) / sum(z.numel() for z in leaves))
     total.backward()
     return float(loss), float(loss_c), p.grad.detach()
+
+
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123) exactly as render_kernels.hip spells it: counter / key as tuples of
+    32-bit words -> 4 output words.  Pinned to the Random123 known-answer vectors in tests/test_host_cpu.py."""
+    m0, m1, w0, w1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, (k0, k1) = list(counter), key
+    for _ in range(10):
+        p0, p1 = m0 * c[0], m1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + w0) & 0xFFFFFFFF, (k1 + w1) & 0xFFFFFFFF
+    return c
+
+
+def philox_uniform(seed, stream_id, n, lo=0.0, hi=1.0):
+    """What pxo_uniform must return: element 4q+i = word i of block (counter = (q, stream_id), key = seed), top 24 bits."""
+    import numpy as np
+    out = np.empty(n, np.float32)
+    for q in range((n + 3) // 4):
+        w = philox4x32_10((q & 0xFFFFFFFF, q >> 32, stream_id & 0xFFFFFFFF, stream_id >> 32), (seed & 0xFFFFFFFF, seed >> 32))
+        for i in range(4):
+            if 4 * q + i < n:
+                r01 = np.float32(w[i] >> 8) * np.float32(1.0 / 16777216.0)
+                out[4 * q + i] = np.float32(lo) + (np.float32(hi) - np.float32(lo)) * r01
+    return out
+
+
+def philox_randint(seed, stream_id, count, n):
+    """What pxo_randint must return: element 2q+i = (word 2i << 32 | word 2i+1) mod n of block q."""
+    import numpy as np
+    out = np.empty(count, np.int64)
+    for q in range((count + 1) // 2):
+        w = philox4x32_10((q & 0xFFFFFFFF, q >> 32, stream_id & 0xFFFFFFFF, stream_id >> 32), (seed & 0xFFFFFFFF, seed >> 32))
+        for i in range(2):
+            if 2 * q + i < count:
+                out[2 * q + i] = ((w[2 * i] << 32) | w[2 * i + 1]) % n
+    return out

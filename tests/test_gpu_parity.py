@@ -371,6 +371,28 @@ def test_uniform():
     assert float(b.min()) >= -1.5 and float(b.max()) < 1.5
 
 
+def test_philox_generators_known_answers():
+    """pxo_uniform / pxo_randint are Philox4x32-10 with counter = (block index, stream id) and key = seed: bit-for-bit the
+    host restatement, which itself reproduces the Random123 known-answer vectors (tests/test_host_cpu.py) - including the
+    first published vector (all-zero counter and key) as elements 0..3 of uniform(seed 0, stream 0)."""
+    from _helpers import philox_randint, philox_uniform
+    ops = _ops(); dev = _gpu()
+    kat = np.array([0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8], np.uint64)
+    got = ops.uniform(0, 0, 4, device=dev).cpu().numpy()
+    assert np.array_equal(got, ((kat >> np.uint64(8)).astype(np.float32) / np.float32(16777216.0)))
+    for seed, stream, n, lo, hi in ((0, 0, 4, 0.0, 1.0), (0x299F31D0A4093822, 0x0370734413198A2E, 1003, 0.0, 1.0),
+                                    (20200823, 7, 257, -1.5, 1.5), (2 ** 64 - 1, 2 ** 64 - 1, 9, 2.0, 6.0)):
+        got = ops.uniform(seed, stream, n, lo, hi, device=dev).cpu().numpy()
+        want = philox_uniform(seed, stream, n, lo, hi)
+        if (lo, hi) == (0.0, 1.0):
+            assert np.array_equal(got, want), (seed, stream, n)                    # the 24-bit draw itself: exact
+        else:                                                                        # lo + (hi - lo) r is one fma on the device
+            assert np.abs(got - want).max() <= 1.5e-7 * (hi - lo) and got.min() >= lo and got.max() < hi, (seed, stream, n)
+    for seed, stream, count, n in ((0, 0, 2, 2 ** 40), (5, 3, 1001, 640000), (2 ** 63 + 11, 2 ** 40 + 1, 7, 10)):
+        got = ops.randint(seed, stream, count, n, device=dev).cpu().numpy()
+        assert np.array_equal(got, philox_randint(seed, stream, count, n)), (seed, stream, count, n)
+
+
 def test_adam_step():
     ops = _ops(); dev = _gpu()
     gen = torch.Generator().manual_seed(31)

@@ -272,3 +272,15 @@ def test_device_helpers_on_the_host(tmp_path, golden_dir):
     res = subprocess.run([exe, raw], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "dirs 64 " in res.stdout and "layout_bad 0" in res.stdout
+
+
+def test_philox_emulator_against_random123_known_answers():
+    """The Philox4x32-10 restatement the GPU generators are compared with (tests/_helpers.py) reproduces the published
+    Random123 known-answer vectors (kat_vectors: philox4x32 10)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _helpers import philox4x32_10
+    assert philox4x32_10((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]

@@ -11,7 +11,6 @@ import sys
 import numpy as np
 import torch
 
-from .. import ops
 from . import isosurface
 from .nerf import models, utils
 

@@ -1,8 +1,6 @@
 """plenoctree_amd.octree.compression and the median-cut quantiser behind `_C.quantize_median_cut`
 (reference call site: octree/compression.py:88-136).  The reference's own driver running on this quantiser is in
 tests/test_reference_drivers_cpu.py; here: the quantiser's contract and the file round trip, without the reference tree."""
-import os
-
 import numpy as np
 import pytest
 import torch

@@ -81,7 +81,7 @@ def flags_for(preset, batch):
     return args
 
 
-def cpu_baseline(args_ns, n_rays, n_steps):
+def cpu_baseline(args_ns, n_rays, n_steps, device):
     """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores
     on a bounded sample of the same workload: `n_rays` rays x (64+128) samples + 10k sparsity
     points, forward + backward + Adam, float32, torch CPU threads = all cores."""
@@ -90,7 +90,14 @@ def cpu_baseline(args_ns, n_rays, n_steps):
     cfg = O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far,
                 sparsity_length=args_ns.sparsity_length, sparsity_radius=args_ns.sparsity_radius)
     gen = torch.Generator().manual_seed(0)
-    ds = datasets.Synthetic("train", args_ns, torch.device("cpu"), batch_size=n_rays)
+    # the same feeder as the GPU legs (batches are drawn on the device and copied to the host before the clock starts)
+    ds_dev = datasets.Synthetic("train", args_ns, device, batch_size=n_rays)
+
+    class _HostBatches:
+        def __next__(self):
+            b = next(ds_dev)
+            return {"rays": type(b["rays"])(*[t.cpu() for t in b["rays"]]), "pixels": b["pixels"].cpu()}
+    ds = _HostBatches()
 
     def step_once(flat, m, v, step, batch):
         rays = O.Rays(*batch["rays"])
@@ -393,7 +400,7 @@ def main():
         }
         out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tr["args"], a.cpu_rays, a.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(tr["args"], a.cpu_rays, a.cpu_steps, job.device)
         print(json.dumps(out), flush=True)
     if job.dist:
         job.dist.barrier()

@@ -137,7 +137,13 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or os.environ.get("PXO_LIB") or LIB_PATH
+    if path is None and os.environ.get("PXO_LIB"):
+        # a variant library (kernel A/B sessions, scripts/) is only honoured when explicitly allowed: nothing that
+        # is benchmarked or tested by default can pick up anything but the in-tree build
+        if os.environ.get("PXO_ALLOW_VARIANT") != "1":
+            raise PxoError("PXO_LIB is set but PXO_ALLOW_VARIANT != 1: refusing to load a variant kernel library")
+        path = os.environ["PXO_LIB"]
+    path = path or LIB_PATH
     # torch must load (and initialise) its HIP runtime first: the library then binds to the same
     # libamdhip64 instance, so device pointers and streams are shared with torch.
     import torch

@@ -87,27 +87,3 @@ def _build(force, verbose, extra_flags, objdir):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    if "--variants" in sys.argv:   # A/B libraries for one GPU session (selected at run time with PXO_LIB)
-        build(suffix="_bd2", extra_flags=("-DPXO_BDIST=2",))     # weight fragments fetched 2 k-groups ahead (3 = default)
-        build(suffix="_nohalf", extra_flags=("-DPXO_NO_HALF_TILES",))    # ragged last round as full tiles
-    if "--variants2" in sys.argv:
-        build(suffix="_mask0", extra_flags=("-DPXO_MASK_ASM=0",))        # relu mask built with shift/or/select
-    if "--x3-variants" in sys.argv:
-        build(suffix="_x3g0", extra_flags=("-DPXO_X3_GEOM=0",))          # split-precision forward: 128-row tiles, 8 waves
-    if "--x3-ablations" in sys.argv:   # timing only, results wrong
-        for a in (1, 2, 3, 4):
-            build(suffix=f"_x3a{a}", extra_flags=(f"-DPXO_X3_ABL={a}",))
-    if "--wgrad-batch" in sys.argv:
-        build(suffix="_wb0", extra_flags=("-DPXO_WGRAD_BATCH=0",))       # one 256x256 wgrad launch per layer (round-2a)
-    if "--oct-k16" in sys.argv:
-        build(suffix="_ok16_0", extra_flags=("-DPXO_OCT_K16=0",))        # forward renderer without the SH16 fast path
-        build(suffix="_och0", extra_flags=("-DPXO_OCT_CH=0", "-DPXO_OCT_K16=0"))   # ... and without channel-aligned ownership
-    if "--oct-vec" in sys.argv:
-        build(suffix="_ovec0", extra_flags=("-DPXO_OCT_VEC=0",))         # forward renderer with dword coefficient loads
-    if "--oct-ablations" in sys.argv:  # timing only, results wrong: octree backward without / with plain-store scatter
-        for a in (1, 2, 3):
-            build(suffix=f"_octa{a}", extra_flags=(f"-DPXO_OCT_ABL={a}",))
-    if "--trace" in sys.argv:      # cycle-stamped wgrad kernel (timing experiment)
-        build(suffix="_wtrace", extra_flags=("-DPXO_TRACE_WGRAD",))
-    if "--ablations" in sys.argv:  # timing-only experiments (results are wrong)
-        build(suffix="_abl_nostore", extra_flags=("-DPXO_ABLATE_STORE",))   # fused MLP kernels without the tile copy to HBM

@@ -201,19 +201,17 @@ __device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int 
   for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
 }
 
-// B (weights, L2 latency) is fetched PXO_BDIST k-groups ahead into four rotating register sets, A (LDS)
+// B (weights, L2 latency) is fetched kBDist k-groups ahead into four rotating register sets, A (LDS)
 // one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
 // sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
 // each load to just before its use and exposes the LDS/L2 latency on every k-group.
-#ifndef PXO_BDIST
-#define PXO_BDIST 3      // k-groups of look-ahead for the weight fragments (2 or 3; four register sets either way)
-#endif
+constexpr int kBDist = 3;   // k-groups of look-ahead for the weight fragments (2 measured 0.25 % slower; four register sets either way)
 #define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
-  constexpr int D = PXO_BDIST;
-  static_assert(D == 2 || D == 3, "PXO_BDIST");
+  constexpr int D = kBDist;
+  static_assert(D == 2 || D == 3, "kBDist");
   f32x4 a0[RBN], a1[RBN], b[4][CBN];
   const int last = kgroups - 1;
   auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
@@ -290,9 +288,6 @@ __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 
 template <int RBN>
 __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
                                            int64_t M, bool full, int tid) {
-#ifdef PXO_ABLATE_STORE        // timing experiment only (results are wrong): what the LDS -> HBM tile copy costs
-  return;
-#endif
 #pragma unroll
   for (int i = 0; i < 32 * RBN * kW / 4 / kMlpThreads; ++i) {
     const int idx = tid + kMlpThreads * i;
@@ -306,26 +301,13 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ lds, float*
 // relu mask, one bit per accumulator element in (row block, column block, register) order, packed MSB-first:
 // the forward epilogue shifts the bit "v > 0" in from the carry (mw = 2 mw + bit: compare + add-with-carry), the
 // backward epilogue shifts it out again into the carry that selects the gradient (add + select).
-#ifndef PXO_MASK_ASM
-#define PXO_MASK_ASM 1
-#endif
 __device__ __forceinline__ void mask_push(uint32_t& mw, float v) {
-#if PXO_MASK_ASM
   asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mw) : "v"(v) : "vcc");
-#else
-  mw = (mw << 1) | (v > 0.f ? 1u : 0u);
-#endif
 }
 __device__ __forceinline__ float mask_pop(uint32_t& mw, float x) {
-#if PXO_MASK_ASM
   float r;
   asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc" : "+v"(mw), "=v"(r) : "v"(x) : "vcc");
   return r;
-#else
-  const float r = (mw & 0x80000000u) ? x : 0.f;
-  mw <<= 1;
-  return r;
-#endif
 }
 
 constexpr int kRB = kTM / 32;                    // row blocks of a full tile (all owned by every wave)

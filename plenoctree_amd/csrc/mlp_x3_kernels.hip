@@ -115,21 +115,14 @@ int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipSt
 // ------------------------------------------------------------------------------------------
 struct X3Frag { bf16x8 hi, lo; };
 
-// Geometry (build-time, PXO_X3_GEOM):
+// Geometry (both were built and measured; 1 is what ships):
 //   0: 128-row tiles, one 8-wave workgroup per CU, every wave 128 rows x 32 features (the f32 kernel's geometry)
 //   1: 64-row tiles, TWO independent 4-wave workgroups per CU, every wave 64 rows x 64 features.  Per MFMA it reads half
 //      as many activation fragments from LDS and twice as many weight fragments from L2; the two workgroups drift
 //      apart, so one's posenc / epilogue / prologue phases run under the other's MFMAs.  With the three bf16 passes
 //      costing 3/16 of the f32 GEMM those phases are no longer small against the GEMM, which is why the geometry that
 //      lost for f32 (138 vs 150 TFLOP/s in the bare-loop probe) is measured here.
-#ifndef PXO_X3_GEOM
-#define PXO_X3_GEOM 1
-#endif
-#if PXO_X3_GEOM == 0
-constexpr int kXRows = 128, kXWaves = 8, kXCB = 1, kXWgPerCu = 1;
-#else
 constexpr int kXRows = 64, kXWaves = 4, kXCB = 2, kXWgPerCu = 2;
-#endif
 constexpr int kXThreads = kXWaves * 64;
 constexpr int kXRB = kXRows / 32;
 
@@ -187,27 +180,9 @@ __device__ __forceinline__ void gemm_x3(const __bf16* __restrict__ xh, const __b
 #pragma unroll
     for (int i = 0; i < 3; ++i) load_w<CBN>(wp, cl(i), kg_stride, w[i]);
   }
-#ifndef PXO_X3_ABL
-#define PXO_X3_ABL 0            // timing-only ablations (results wrong): 1 posenc, 2 epilogue, 3 LDS operand reads, 4 weight loads
-                                // (measured, 2.10 ms base: 1.61 / - / 2.04 / 1.73 ms; the fast-sin experiment showed the posenc cost is not the sin)
-#endif
-#if PXO_X3_ABL == 3
-#define LOADX(g, x) asm volatile("" : "+v"(x[0].hi), "+v"(x[0].lo))
-#else
 #define LOADX(g, x) load_x<RBN>(xh, xl, g, x)
-#endif
-#if PXO_X3_ABL == 4
-#define LOADW(g, ww) asm volatile("" : "+v"(ww[0].hi), "+v"(ww[0].lo))
-#else
 #define LOADW(g, ww) load_w<CBN>(wp, cl(g), kg_stride, ww)
-#endif
   load_x<RBN>(xh, xl, 0, x0);
-#if PXO_X3_ABL == 3
-  load_x<RBN>(xh, xl, 1, x1);
-#endif
-#if PXO_X3_ABL == 4
-  load_w<CBN>(wp, 0, kg_stride, w[3]);
-#endif
   for (int g = 0; g < kgroups; g += 4) {
     LOADX(g + 1, x1);
     LOADW(g + 3, w[3]);
@@ -256,9 +231,6 @@ __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* 
   static_assert(kXThreads / kXRows == 4, "4 parts x 16 columns");
   const int row = tid % kXRows, part = tid / kXRows;
   const int64_t grow = row0 + row;
-#if PXO_X3_ABL == 1
-  if (grow >= 0) return;
-#endif
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
   if (grow < M) {
     if (grid.enabled) {
@@ -338,9 +310,6 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
       }
       __syncthreads();  // every wave has consumed the input planes
       // epilogue: lane holds features n0 .. n0+3 of sample m per register quad
-#if PXO_X3_ABL == 2
-      asm volatile("" :: "v"(acc[0][0]), "v"(acc[kXRB - 1][kXCB - 1]));
-#else
 #pragma unroll
       for (int r = 0; r < kXRB; ++r) {
         const int m = r * 32 + (lane & 31);
@@ -357,7 +326,6 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
             *reinterpret_cast<uint2*>(plane_l + m * kLDB + n0) = make_uint2(l01, l23);
           }
       }
-#endif
       __syncthreads();
     }
 

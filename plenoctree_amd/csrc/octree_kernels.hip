@@ -423,21 +423,6 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 constexpr int kRenderThreads = 256;
 
-#ifndef PXO_OCT_ABL
-#define PXO_OCT_ABL 0
-#endif
-#ifndef PXO_OCT_BWD4
-#define PXO_OCT_BWD4 1            // backward at "4 lanes per ray": 4-lane march + 16-lane cooperative scatter (0: the plain 4-lane kernel)
-#endif
-#ifndef PXO_OCT_CH
-#define PXO_OCT_CH 1              // forward renderer at 4 lanes per ray: channel-aligned coefficient ownership for every K (0: A/B)
-#endif
-#ifndef PXO_OCT_K16
-#define PXO_OCT_K16 1             // ... with K a compile-time constant per SH format (0: run-time K, for A/B)
-#endif
-#ifndef PXO_OCT_VEC
-#define PXO_OCT_VEC 1             // forward renderer: leaf coefficients as 16-byte loads per lane (0: one dword per lane per load)
-#endif
 // lanes per ray: ROW in {4, 8, 16}; the wave carries 64/ROW rays as a WTX x WTY pixel patch
 template <int ROW> struct RowGeom {
   static constexpr int kRaysPerWave = 64 / ROW;
@@ -628,9 +613,6 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     first_pass = 1;
   }
 
-#if PXO_OCT_ABL
-  float abl_acc = 0.0f;
-#endif
   // pass 0 composites; in MODE 1 pass 1 re-marches and scatters the gradient
   for (int pass = first_pass; pass <= MODE; ++pass) {
     Marcher mk;
@@ -735,22 +717,12 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
           for (int j = 0; j < kMaxLoads; ++j) {
             if (j < nload) {
               const int idx = l + kRow * j;
-#if PXO_OCT_ABL == 1 || PXO_OCT_ABL == 2     // timing experiments (results wrong): no coefficient atomics
-              if (idx < D - 1) abl_acc += (b0[j] * d0 + b1[j] * d1) + b2[j] * d2;
-#elif PXO_OCT_ABL == 3                        // plain (racy) stores instead of atomics
-              if (idx < D - 1) gv[idx] = (b0[j] * d0 + b1[j] * d1) + b2[j] * d2;
-#else
               if (idx < D - 1) unsafeAtomicAdd(gv + idx, (b0[j] * d0 + b1[j] * d1) + b2[j] * d2);
-#endif
             }
           }
           light = light * att;
           accum -= weight * total;
-#if PXO_OCT_ABL == 2
-          abl_acc += dtw * (total * light - accum);
-#else
           if (l == 0) unsafeAtomicAdd(gv + D - 1, dtw * (total * light - accum));
-#endif
         }
       }
       const float tn = t + delta_t;
@@ -768,12 +740,9 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
       }
     }
   }
-#if PXO_OCT_ABL
-  if (MODE == 1 && abl_acc == 123.456f) grad_data[0] = abl_acc;
-#endif
 }
 
-// Backward with a 4-lane march and a 16-lane scatter (PXO_OCT_BWD4).  The march is the forward kernel's: 16 rays per wave,
+// Backward with a 4-lane march and a 16-lane scatter.  The march is the forward kernel's: 16 rays per wave,
 // channel-aligned coefficient reads, few registers - the phase that is latency-bound.  The scatter wants the opposite shape
 // (the gradient of a sample is a 3K-float row: 64-byte atomic rows per instruction), so after every march step the wave
 // re-deals itself as 4 rays x 16 lanes, four times: lane (q, j) of deal g fetches the step's row-uniform results of ray
@@ -1268,23 +1237,19 @@ int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float
   const float* none = nullptr;
   switch (row) {
     case 4:
-#define PXO_FWD4(KF_) hipLaunchKernelGGL((octree_render_kernel<0, 4, PXO_OCT_VEC != 0, KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr)
-      if (PXO_OCT_VEC != 0 && PXO_OCT_CH != 0) {
-        switch (PXO_OCT_K16 != 0 ? tree->basis_dim : 0) {
-          case 1: PXO_FWD4(1); break;
-          case 4: PXO_FWD4(4); break;
-          case 9: PXO_FWD4(9); break;
-          case 16: PXO_FWD4(16); break;
-          case 25: PXO_FWD4(25); break;
-          default: PXO_FWD4(-1); break;
-        }
-      } else {
-        PXO_FWD4(0);
+#define PXO_FWD4(KF_) hipLaunchKernelGGL((octree_render_kernel<0, 4, true, KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr)
+      switch (tree->basis_dim) {
+        case 1: PXO_FWD4(1); break;
+        case 4: PXO_FWD4(4); break;
+        case 9: PXO_FWD4(9); break;
+        case 16: PXO_FWD4(16); break;
+        case 25: PXO_FWD4(25); break;
+        default: PXO_FWD4(-1); break;
       }
 #undef PXO_FWD4
       break;
-    case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
-    default: hipLaunchKernelGGL((octree_render_kernel<0, 16, PXO_OCT_VEC != 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    case 8: hipLaunchKernelGGL((octree_render_kernel<0, 8, true>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
+    default: hipLaunchKernelGGL((octree_render_kernel<0, 16, true>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, none, none, (float*)nullptr); break;
   }
   return check_launch("octree_render_fwd");
 }
@@ -1305,7 +1270,6 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
               (double)opts->stop_thresh);
   switch (row) {
     case 4:
-#if PXO_OCT_BWD4
 #define PXO_BWD4(KF_) hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, grad_out, grad_data)
       switch (tree->basis_dim) {
         case 16: PXO_BWD4(16); break;
@@ -1313,9 +1277,6 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
         default: PXO_BWD4(-1); break;
       }
 #undef PXO_BWD4
-#else
-      hipLaunchKernelGGL((octree_render_kernel<1, 4>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data);
-#endif
       break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
     default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;

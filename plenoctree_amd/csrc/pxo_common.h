@@ -97,9 +97,6 @@ __host__ __device__ inline TileSched tile_sched(int64_t M, int64_t grid) {
   TileSched t;
   const int64_t tiles = num_tiles(M);
   t.n_full = tiles; t.n_half = 0; t.half_row0 = tiles * kTM;
-#ifdef PXO_NO_HALF_TILES            // A/B builds: the ragged last round as full tiles
-  return t;
-#endif
   if (grid < 1 || tiles <= grid) return t;
   const int64_t whole = (tiles / grid) * grid;
   const int64_t left = M - whole * kTM;             // > 0 rows after the whole rounds (0 if tiles % grid == 0 and M % 128 == 0)

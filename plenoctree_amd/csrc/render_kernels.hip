@@ -57,7 +57,8 @@ int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, f
   return check_launch("sample_along_rays");
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(kRayThreads) void sample_pdf_kernel(
     float* __restrict__ z_out, float* __restrict__ pts) {
   __shared__ float s_cdf[kRaysPerBlock][kMaxCoarse];
   __shared__ float s_bins[kRaysPerBlock][kMaxCoarse];
-  __shared__ float s_pdf[kRaysPerBlock][kMaxCoarse];
+  __shared__ double s_pdf[kRaysPerBlock][kMaxCoarse];
   __shared__ float s_z[kRaysPerBlock][kMaxCoarse + kMaxFine];
   __shared__ float s_sorted[kRaysPerBlock][kMaxCoarse + kMaxFine];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,27 +300,34 @@ __global__ __launch_bounds__(kRayThreads) void sample_pdf_kernel(
   if (!ray_ok) ray = B - 1;
   const int nb = Nc - 1;   // knots
   const int nw = Nc - 2;   // weights / bins between knots
-  float* cdf = s_cdf[wave]; float* bins = s_bins[wave]; float* pdf = s_pdf[wave];
+  float* cdf = s_cdf[wave]; float* bins = s_bins[wave]; double* pdf = s_pdf[wave];
   float* zall = s_z[wave]; float* sorted = s_sorted[wave];
 
-  float wsum = 0.f;
+  // The weight sum, the pdf and the running cdf are accumulated in float64 and each knot is rounded to float32
+  // once.  In float32 the cdf of a ray that ends on an opaque surface plateaus at 1 - 2^-23 or 1 - 2^-24 depending
+  // on the last ulp of ~60 roundings, and 1 - 2^-23 is exactly the last deterministic sample u = 1 - eps
+  // (model_utils.py:265): `u >= cdf` (:270) then moves that sample from the surface bin to the far end of the
+  // plateau -- one bin width (6e-2) in z and up to 7e-3 in the pixel, for a handful of rays per 4096
+  // (profiles/r03_render_outliers.md).  The exact sum is 1 - O(1e-16), so the float64 oracle never takes that
+  // branch; accumulating in float64 removes the coin toss (and costs nothing: ~60 adds per ray).
+  double wsum = 0.0;
   for (int i = lane; i < Nc; i += 64) {
     const float zi = z_c[ray * Nc + i];
     zall[i] = zi;
     if (i + 1 < Nc) bins[i] = 0.5f * (z_c[ray * Nc + i + 1] + zi);   // models.py:296
-    if (i >= 1 && i <= nw) { const float wi = w_c[ray * Nc + i]; pdf[i - 1] = wi; wsum += wi; }
+    if (i >= 1 && i <= nw) { const double wi = (double)w_c[ray * Nc + i]; pdf[i - 1] = wi; wsum += wi; }
   }
   wsum = wave_sum(wsum);
   // model_utils.py:240-244: pad so that the sum is at least eps
-  const float padding = fmaxf(0.f, 1e-5f - wsum);
-  const float wtot = wsum + padding;
+  const double padding = fmax(0.0, (double)1e-5f - wsum);
+  const double wtot = wsum + padding;
   __syncthreads();
-  for (int i = lane; i < nw; i += 64) pdf[i] = (pdf[i] + padding / (float)nw) / wtot;
+  for (int i = lane; i < nw; i += 64) pdf[i] = (pdf[i] + padding / (double)nw) / wtot;
   __syncthreads();
   if (lane == 0) {  // sequential cumsum keeps the cdf monotone (model_utils.py:248-257)
-    float run = 0.f;
+    double run = 0.0;
     cdf[0] = 0.f;
-    for (int i = 0; i + 1 < nw; ++i) { run += pdf[i]; cdf[i + 1] = fminf(1.f, run); }
+    for (int i = 0; i + 1 < nw; ++i) { run += pdf[i]; cdf[i + 1] = (float)fmin(1.0, run); }
     cdf[nw] = 1.f;
   }
   __syncthreads();

@@ -14,25 +14,7 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
-#ifndef PXO_WGRAD_BATCH
-#define PXO_WGRAD_BATCH 1         // 1: Dense_1..7's products in one launch (0: one launch per layer, for A/B)
-#endif
 
-#ifdef PXO_TRACE_WGRAD
-// cycle stamps of wave 0 of workgroup 0 over a few steady-state chunks (timing experiments only): kept in LDS while the
-// kernel runs (a stamp is s_memtime + ds_write, no wait), flushed at the end
-__device__ unsigned long long g_wtrace[2048];
-__device__ int g_wtrace_n;
-#define WTRACE(id)                                                                                         \
-  do {                                                                                                     \
-    if (KIN == 256 && NOUT == 256 && blockIdx.x == 0 && threadIdx.x == 0 && ch >= 40 && ch < 48 && s_tn < 250) { \
-      s_trace[s_tn] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFull); \
-      s_tn++;                                                                                              \
-    }                                                                                                      \
-  } while (0)
-#else
-#define WTRACE(id)
-#endif
 
 // Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over
 // NSPLIT workgroups (each owns NOUT/NSPLIT output columns and re-reads X; the NSPLIT partners of a
@@ -56,10 +38,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   __shared__ __attribute__((aligned(16))) float xs[2][KCH * KIN];
   __shared__ __attribute__((aligned(16))) float zs[2][KCH * NTILE];
 
-#ifdef PXO_TRACE_WGRAD
-  __shared__ unsigned long long s_trace[256];
-  int s_tn = 0;
-#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
@@ -167,9 +145,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   // chunk held in `stg` into the other LDS buffer (if do_st)
   auto run_chunk = [&](int ch, int buf, Stage& ld, int ld_ch, bool do_ld, const Stage& stg, bool do_st) {
     (void)ch;
-    WTRACE(1);
     if (SCHED == 0 && do_ld) load_chunk(ld_ch, ld);
-    WTRACE(2);
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
@@ -195,7 +171,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      WTRACE(10 + kk);
       // SCHED 1 (the skinny, HBM-heavy products; the 256x256 product measured 2 % slower with it): the loads
       // (address arithmetic + 6 loads) are issued under the first MFMA group of this chunk, the LDS stores under the
       // last one: the stretch between a chunk's last MFMA and the next chunk's first is then only "barrier + first
@@ -208,13 +183,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       if (SCHED != 0 && kk + 4 >= KCH) __builtin_amdgcn_sched_barrier(0);
       mfma_step(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
-      WTRACE(12 + kk);
     }
-    WTRACE(3);
     if (SCHED == 0 && do_st) store_chunk(buf ^ 1, stg);
-    WTRACE(4);
     __syncthreads();
-    WTRACE(5);
   };
 
   {
@@ -230,13 +201,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     }
   }
 
-#ifdef PXO_TRACE_WGRAD
-  if (KIN == 256 && NOUT == 256 && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int base = g_wtrace_n;
-    for (int i = 0; i < s_tn && base + i < 2048; ++i) g_wtrace[base + i] = s_trace[i];
-    g_wtrace_n = base + s_tn;
-  }
-#endif
   float* out = slab + (int64_t)p * KIN * NOUT;
 #pragma unroll
   for (int r = 0; r < RB; ++r)
@@ -251,71 +215,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     }
 }
 
-// dst[i*dst_ld + (n-col0)] = sum_p slab[p][i][n]   for i < rows_valid, col0 <= n < col0+ncols.
-// Block = 64 float4 columns x 4 partial groups: thread (q, v) adds slabs p = q, q+4, ... for the
-// float4 at element 4*(64*blockIdx.x + v); the four partial sums are combined through LDS in a
-// fixed order (deterministic).  16 B loads, P/4 of them per thread.
-// A second destination (dst2: columns [col0_2, col0_2+ncols) of the same rows) lets one pass over the slabs feed two
-// parameter leaves (the dual-source kernel above).
-__global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int P, int kin, int nout,
-                                                          int rows_valid, int col0, int ncols,
-                                                          float* __restrict__ dst, int dst_ld,
-                                                          float* __restrict__ dst2, int col0_2) {
-  __shared__ f32x4 red[4][64];
-  const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t e4 = (int64_t)blockIdx.x * 64 + v;            // float4 index inside one slab
-  const int64_t stride4 = (int64_t)kin * nout / 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (e4 < stride4) {
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(slab) + e4;
-#pragma unroll 8
-    for (int p = q; p < P; p += 4) s += src[p * stride4];
-  }
-  red[q][v] = s;
-  __syncthreads();
-  if (q == 0 && e4 < stride4) {
-    f32x4 t = red[0][v];
-    t += red[1][v]; t += red[2][v]; t += red[3][v];
-    const int64_t e = e4 * 4;
-    const int i = (int)(e / nout), n0 = (int)(e % nout);
-    if (i < rows_valid) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + j;
-        if (n >= col0 && n < col0 + ncols) dst[(int64_t)i * dst_ld + (n - col0)] = t[j];
-        else if (dst2 && n >= col0_2 && n < col0_2 + ncols) dst2[(int64_t)i * dst_ld + (n - col0_2)] = t[j];
-      }
-    }
-  }
-}
-
-// bias gradients: fixed-order sum of the per-workgroup partials written by mlp_bwd_data_kernel.
-// block = (layer 0..8, 32-column group); thread (tsub, c) sums tiles == tsub mod 8.
-__global__ void reduce_dbias_kernel(const float* __restrict__ partial, int64_t ntiles, int deg,
-                                    float* __restrict__ grads) {
-  __shared__ float red[8][32];
-  const int l = blockIdx.x / 8, cg = blockIdx.x % 8;
-  const int c = threadIdx.x & 31, tsub = threadIdx.x >> 5;
-  const int col = cg * 32 + c;
-  float s = 0.f;
-  for (int64_t t = tsub; t < ntiles; t += 8) s += partial[(t * 9 + l) * kW + col];
-  red[tsub][c] = s;
-  __syncthreads();
-  if (tsub == 0) {
-    float tot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tot += red[i][c];
-    if (l < 8) {
-      grads[leaf_bias_off(l, deg) + col] = tot;
-    } else {
-      const int C = rgb_channels(deg);
-      if (col < C) grads[leaf_bias_off(9, deg) + col] = tot;
-      else if (col == C) grads[leaf_bias_off(8, deg)] = tot;
-    }
-  }
-}
-
-// One launch for every slab reduction of a weight-gradient pass (PXO_WGRAD_BATCH): blockIdx.y selects the job.
+// One launch for every slab reduction of a weight-gradient pass: blockIdx.y selects the job.
 // A job sums P slabs of kin x nout and scatters column ranges A and B of the first rows_valid rows to two leaves.
 struct ReduceJob {
   const float* slab;
@@ -399,13 +299,9 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
   // 2 num_cus() (the skinny products run two workgroups per CU); the size does not depend on M (two passes of
   // different M share one workspace)
   (void)cfg; (void)M;
-#if PXO_WGRAD_BATCH
   // Dense_1..7 in one launch: a slab set per layer; then the enc-based pair's and the heads' slabs (all reduced together)
   return ((size_t)(kDepth - 1) * num_cus() * kW * kW + (size_t)2 * num_cus() * kEncPad * 2 * kW +
           (size_t)2 * num_cus() * kW * 32 * 3) * sizeof(float);
-#else
-  return (size_t)num_cus() * kW * kW * sizeof(float);
-#endif
 }
 
 template <int NHB>
@@ -453,7 +349,6 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   float* const g5skip = grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW;
   float* const g8 = grads + leaf_kernel_off(8, deg);
   float* const g9 = grads + leaf_kernel_off(9, deg);
-#if PXO_WGRAD_BATCH
   // Dense_1..7: h_{l-1}^T dz_l (for l = 5 these are the first 256 input rows) in ONE launch: acts and dz are [8][M,256]
   // stacks, so layer l is "group l-1" of the kernel with layer_stride = M*256; then ONE launch reduces every slab set of
   // the pass (and the bias partials).  14 + 12 launches per step fewer than a launch per product, and the layers'
@@ -489,46 +384,8 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   J.deg = deg;
   J.grads = grads;
   hipLaunchKernelGGL(reduce_jobs_kernel, dim3(kW * kW / 4 / 64, kDepth + 2), dim3(256), 0, s, J);
-#else
-  // one launch per product, each followed by its slab reduce (round 2a; kept for A/B)
-  float* slab = reinterpret_cast<float*>(ws);
-  int64_t rpw; int P;
-  split_rows(M, num_cus(), &rpw, &P);
-  auto reduce2 = [&](int np, int kin, int nout, int rows_valid, int col0, int ncols, float* dst, int dst_ld, float* dst2,
-                     int col0_2) {
-    const int n4 = kin * nout / 4;
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((n4 + 63) / 64), dim3(256), 0, s, slab, np, kin, nout,
-                       rows_valid, col0, ncols, dst, dst_ld, dst2, col0_2);
-  };
-  enc_pair(slab);
-  reduce2(P2, kEncPad, 2 * kW, kEnc, 0, kW, g0, kW, g5skip, kW);
-  for (int l = 1; l < kDepth; ++l) {
-    {
-      KernelTimer timer(PXO_PROF_WGRAD_MAIN, M, s);
-      // 256x256 product as two independent 4-wave workgroups per CU (256 x 128 each, 16-row chunks)
-      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(((P + 7) / 8) * 16), dim3(256), 0, s,
-                         acts + (int64_t)(l - 1) * MW, dz + (int64_t)l * MW, nullptr, 0, M, rpw, P, slab);
-    }
-    reduce2(P, kW, kW, kW, 0, kW, grads + leaf_kernel_off(l, deg), kW, nullptr, 0);
-  }
-  head(slab);
-  reduce2(P2, kW, 32 * nhb, kW, 0, C, g9, C, nullptr, 0);
-  reduce2(P2, kW, 32 * nhb, kW, C, 1, g8, 1, nullptr, 0);
-  hipLaunchKernelGGL(reduce_dbias_kernel, dim3(9 * 8), dim3(256), 0, s, dbias_partial, (int64_t)mlp_bwd_partials(M), deg, grads);
-#endif
   return check_launch("mlp_bwd_weights");
 }
 
-#ifdef PXO_TRACE_WGRAD
-extern "C" int pxo_debug_wtrace(unsigned long long* out, int cap, int reset) {
-  int n = 0;
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wtrace_n), sizeof(int));
-  if (n > cap) n = cap;
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), sizeof(unsigned long long) * n);
-  if (reset) { int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace_n), &z, sizeof(int)); }
-  return n;
-}
-#endif
 
 }  // namespace pxo

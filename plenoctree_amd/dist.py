@@ -35,6 +35,17 @@ class Comm:
         torch.distributed.all_gather_into_tensor(out, t.contiguous())
         return out
 
+    def all_gather_into(self, out, t):
+        """all_gather of equal-size contiguous `t` straight into the flat tensor `out` (world * t.numel())."""
+        if not self.is_dist:
+            out.copy_(t.reshape(-1))
+            return out
+        src = t.reshape(-1)
+        if self.backend != "nccl":        # RCCL gathers in place when `t` is this rank's slice of `out`; gloo gets a copy
+            src = src.clone()
+        torch.distributed.all_gather_into_tensor(out, src)
+        return out
+
     def barrier(self):
         if self.is_dist:
             torch.distributed.barrier()

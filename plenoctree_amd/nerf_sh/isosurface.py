@@ -91,6 +91,8 @@ def marching_cubes(vol, iso):
     shape = vol.shape
     if min(shape) < 2:
         return np.zeros((0, 3)), np.zeros((0, 3), np.int64)
+    if not np.isfinite(vol).all():
+        raise ValueError("marching_cubes: the volume holds non-finite values (NaN/inf sigma would give NaN vertices)")
     inside = vol >= iso
 
     # vertices: one per grid edge whose end points straddle iso, numbered axis by axis

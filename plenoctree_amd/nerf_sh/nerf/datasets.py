@@ -53,12 +53,38 @@ def analytic_scene_rgb(origins, directions, white_bkgd=True):
     return color.float()
 
 
+class HipFeeder:
+    """Batch sampling and ray generation on the MI355X (pxo_randint, pxo_generate_rays[_multi]): no host->device
+    copy inside the step loop, so the host never waits for the GPU and launches run ahead of the kernels.  This is the
+    only feeder of the product; the CPU host-logic tests install their own (tests/_cpu_feeder.py) through
+    `Dataset.feeder_factory`."""
+    resident_images = True        # Synthetic renders its training views once and keeps them on the device
+
+    def __init__(self, device):
+        if device.type != "cuda":
+            raise RuntimeError("datasets: the ray/pixel feeder runs on a ROCm device only (no CPU fallback)")
+        from ... import ops
+        self.ops, self.device = ops, device
+
+    def randint(self, seed, draw, count, n):
+        """`count` ids uniform in [0, n) from Philox stream `draw` of `seed` (np.random.randint, datasets.py:160-166)."""
+        return self.ops.randint(seed, draw, count, n, device=self.device)
+
+    def generate_rays(self, c2w, w, h, focal, ray_indices):
+        return self.ops.generate_rays(c2w, w, h, focal, ray_indices)
+
+    def generate_rays_multi(self, c2w_all, w, h, focal, ray_ids):
+        return self.ops.generate_rays_multi(c2w_all, w, h, focal, ray_ids)
+
+
 class Dataset:
     """Iterator yielding {"pixels": [B,3], "rays": Rays([B,3] x3)} on `device`."""
+    feeder_factory = HipFeeder
 
     def __init__(self, split, args, device, batch_size=None, seed=20201473):
         self.split = split
         self.device = device
+        self.feeder = type(self).feeder_factory(device)
         self.batch_size = batch_size if batch_size is not None else args.batch_size
         self.white_bkgd = bool(args.white_bkgd)
         self.image_batching = bool(getattr(args, "image_batching", False))
@@ -66,6 +92,7 @@ class Dataset:
         self.seed, self.draws = int(seed), 0
         self.it = 0
         self._load(args)
+        self._c2w_dev = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[:, :3, :4])).to(self.device)
 
     # subclasses set: self.camtoworlds [n,4,4] float32, self.h, self.w, self.focal, self.n_examples
     def _load(self, args):
@@ -80,20 +107,9 @@ class Dataset:
 
     def _rays_for(self, image_index, ray_indices):
         """Rays of the chosen pixels of one image (generate_rays, utils.py:545-589), on device."""
-        if self.device.type == "cuda":      # HIP kernel; the torch expression below is the CPU-test path
-            from ... import ops
-            if not hasattr(self, "_c2w_dev"):
-                self._c2w_dev = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[:, :3, :4])).to(self.device)
-            return utils.Rays(*ops.generate_rays(self._c2w_dev[image_index], self.w, self.h, self.focal, ray_indices))
-        c2w = torch.from_numpy(self.camtoworlds[image_index]).to(self.device)
-        idx = ray_indices
-        x = (idx % self.w).float()
-        y = torch.div(idx, self.w, rounding_mode="floor").float()
-        cam = torch.stack([(x - self.w * 0.5) / self.focal, -(y - self.h * 0.5) / self.focal, -torch.ones_like(x)], -1)
-        directions = cam @ c2w[:3, :3].T
-        origins = c2w[:3, 3].expand_as(directions).contiguous()
-        viewdirs = directions / directions.norm(dim=-1, keepdim=True)
-        return utils.Rays(origins, directions.contiguous(), viewdirs.contiguous())
+        c2w = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[image_index, :3, :4])).to(self.device) \
+            if getattr(self, "_c2w_dev", None) is None else self._c2w_dev[image_index]
+        return utils.Rays(*self.feeder.generate_rays(c2w, self.w, self.h, self.focal, ray_indices))
 
     def __iter__(self):
         return self
@@ -104,14 +120,8 @@ class Dataset:
         if self.split == "train":
             # datasets.py:159-166: one random image, batch_size random pixels (with replacement)
             image_index = int(self.rng.randint(0, self.n_examples))
-            if self.device.type == "cuda":
-                # pixel ids drawn on the device (Philox): no host->device copy, so the host never waits for the
-                # GPU inside the step loop and launches run ahead of the kernels
-                from ... import ops
-                self.draws += 1
-                ray_indices = ops.randint(self.seed, self.draws, self.batch_size, self.h * self.w, device=self.device)
-            else:
-                ray_indices = torch.from_numpy(self.rng.randint(0, self.h * self.w, (self.batch_size,))).to(self.device)
+            self.draws += 1
+            ray_indices = self.feeder.randint(self.seed, self.draws, self.batch_size, self.h * self.w)
             rays = self._rays_for(image_index, ray_indices)
             return {"pixels": self._pixels_for(image_index, ray_indices, rays), "rays": rays}
         idx = self.it
@@ -122,19 +132,9 @@ class Dataset:
         """image_batching (datasets.py:137-141,152-157): batch_size rays drawn from the flattened table of the rays
         of ALL images.  The table itself is never materialised: a ray id is (camera, pixel) and the ray is computed."""
         hw = self.h * self.w
-        if self.device.type == "cuda":
-            from ... import ops
-            self.draws += 1
-            ids = ops.randint(self.seed, self.draws, self.batch_size, self.n_examples * hw, device=self.device)
-            if not hasattr(self, "_c2w_dev"):
-                self._c2w_dev = torch.from_numpy(np.ascontiguousarray(self.camtoworlds[:, :3, :4])).to(self.device)
-            rays = utils.Rays(*ops.generate_rays_multi(self._c2w_dev, self.w, self.h, self.focal, ids))
-        else:
-            ids = torch.from_numpy(self.rng.randint(0, self.n_examples * hw, (self.batch_size,))).to(self.device)
-            cam = torch.div(ids, hw, rounding_mode="floor")
-            parts = [self._rays_for(int(c), ids[cam == c] - int(c) * hw) for c in torch.unique(cam).tolist()]
-            order = torch.argsort(torch.cat([torch.nonzero(cam == c).reshape(-1) for c in torch.unique(cam).tolist()]))
-            rays = utils.Rays(*[torch.cat([getattr(p, f) for p in parts])[order].contiguous() for f in utils.Rays._fields])
+        self.draws += 1
+        ids = self.feeder.randint(self.seed, self.draws, self.batch_size, self.n_examples * hw)
+        rays = utils.Rays(*self.feeder.generate_rays_multi(self._c2w_dev, self.w, self.h, self.focal, ids))
         return {"pixels": self._pixels_flat(ids, rays), "rays": rays}
 
     def _pixels_flat(self, ids, rays):
@@ -169,7 +169,7 @@ class Synthetic(Dataset):
         self.camtoworlds = np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(n)])
         self.n_examples = n
         self.images = None
-        if self.split == "train" and self.device.type == "cuda":
+        if self.split == "train" and self.feeder.resident_images:
             ids = torch.arange(self.h * self.w, device=self.device)
             chunks = []
             for i0 in range(0, n, 20):                     # 20 views per evaluation of the analytic scene

@@ -43,17 +43,20 @@ def main(argv=None):
     if comm.rank == 0:
         print("Average PSNR", psnr, "SSIM", ssim, flush=True)
     if args.write_vid is not None and frames:
-        # imageio / ffmpeg are not installed: this rank's frames as an animated GIF at the requested path's stem
+        # imageio / ffmpeg are not installed: this rank's frames (every world-th view) as an animated GIF
         from PIL import Image
-        path = os.path.splitext(args.write_vid)[0] + (".gif" if comm.world == 1 else f".rank{comm.rank}.gif")
+        if os.path.splitext(args.write_vid)[1].lower() != ".gif":
+            raise ValueError(f"--write_vid {args.write_vid}: only animated GIF output is built (no imageio/ffmpeg here); "
+                             "give a .gif path")
+        path = args.write_vid if comm.world == 1 else os.path.splitext(args.write_vid)[0] + f".rank{comm.rank}.gif"
         print("Writing to", path, flush=True)
-        ims = [Image.fromarray((im.numpy() * 255).astype(np.uint8)) for _, im in frames]
+        ims = [Image.fromarray(im.numpy()) for _, im in frames]
         ims[0].save(path, save_all=True, append_images=ims[1:], duration=50, loop=0)
     if args.write_images is not None:
         from PIL import Image
         os.makedirs(args.write_images, exist_ok=True)
         for idx, im in frames:
-            Image.fromarray((im.numpy() * 255).astype(np.uint8)).save(os.path.join(args.write_images, f"{idx:03d}.png"))
+            Image.fromarray(im.numpy()).save(os.path.join(args.write_images, f"{idx:03d}.png"))
     comm.shutdown()
     return psnr
 

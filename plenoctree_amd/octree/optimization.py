@@ -4,10 +4,12 @@ the training images through the octree renderer.
 Per image (reference :214-230): render -> clamp -> MSE -> backward -> optimizer step.  Here: HIP render
 forward, HIP clamped-MSE gradient, HIP render backward (atomic scatter into the tree gradient), HIP SGD/Adam.
 With N GPUs each image's gradient is computed on one rank in turn and summed with one RCCL all-reduce per
-group of N images; N = 1 reproduces the reference's per-image steps.  `--dp_grad_reduce sum` (default) applies the
-SUM of the group's gradients at the unchanged lr -- to first order the reference's N consecutive per-image steps
-(linear lr scaling), so an epoch moves the tree as far as on one GPU; `mean` averages instead (an N-image
-mini-batch at the same lr: N times smaller effective updates per epoch).  Adam is invariant to the choice.
+group of N images; N = 1 reproduces the reference's per-image steps.  `--dp_grad_reduce mean` (default) averages the
+group's gradients: an N-image mini-batch at the reference's learning rate (N times fewer, equally long steps per
+epoch -- safe at the reference's lr of ~1e7, which is tuned for single-image steps).  `sum` applies the SUM at the
+unchanged lr -- to first order the reference's N consecutive per-image steps, i.e. an N times larger step from one
+point; it can overshoot or trip the "Stop since overfitting" break and is opt-in (a warning is printed).  Adam is
+invariant to the choice.
 
     python -m plenoctree_amd.octree.optimization --input tree.npz --output tree_opt.npz --config blender --data_dir ...
 """
@@ -43,7 +45,7 @@ def define_flags():
     a("--continue_on_decrease", action="store_true")
     a("--renderer_step_size", type=float, default=1e-4)
     a("--no_early_stop", action="store_true")
-    a("--dp_grad_reduce", type=str, default="sum", choices=["sum", "mean"])     # multi-GPU only (see module doc)
+    a("--dp_grad_reduce", type=str, default="mean", choices=["sum", "mean"])     # multi-GPU only (see module doc)
     return p
 
 
@@ -108,6 +110,9 @@ def fit(args, tree, train, val, H, W, focal, comm, say=print):
     renderer = VolumeRenderer(tree, step_size=args.renderer_step_size)
     opt = TreeOptimizer(tree, args)
     say("Using SGD, lr" if args.sgd else "Using Adam, lr", args.lr, flush=True)
+    if comm.world > 1 and args.sgd and getattr(args, "dp_grad_reduce", "mean") == "sum":
+        say(f"warning: --dp_grad_reduce sum applies {comm.world} images' summed gradient at lr {args.lr} "
+            "(the reference's lr is tuned for single-image steps)", flush=True)
     vis_dir = None
     if getattr(args, "render_interval", 0) > 0:
         vis_dir = os.path.splitext(args.input)[0] + "_render"                    # :163-164
@@ -127,7 +132,7 @@ def fit(args, tree, train, val, H, W, focal, comm, say=print):
                 tpsnr += -10.0 * torch.log10(sse.double().reshape(()) / (H * W * 3))   # device-side, read once per epoch
             n_imgs = min(comm.world, n_train - j0)
             comm.all_reduce_sum(opt.grad)
-            opt.step(grad_scale=1.0 if getattr(args, "dp_grad_reduce", "sum") == "sum" else 1.0 / n_imgs)
+            opt.step(grad_scale=1.0 if getattr(args, "dp_grad_reduce", "mean") == "sum" else 1.0 / n_imgs)
         comm.all_reduce_sum(tpsnr)
         train_psnr = float(tpsnr) / n_train
         say("epoch", epoch, "** train_psnr", train_psnr, flush=True)

@@ -494,7 +494,13 @@ class VolumeRenderer:
         octree/optimization.py:216) is differentiable; the early-stopping preset (fast=True, evaluation) never is."""
         c2w = torch.as_tensor(c2w, dtype=torch.float32, device=self.tree.device)
         data = self.tree.data
-        if torch.is_grad_enabled() and data.requires_grad and not fast:
+        if torch.is_grad_enabled() and data.requires_grad:
+            if fast:
+                # every fast=True call site of the reference sits under torch.no_grad() (octree/nerf/utils.py:276,
+                # octree/evaluation.py:73); silently returning a detached image would surface later as an obscure
+                # "does not require grad" error in the caller's backward
+                raise oops.PxoError("render_persp(fast=True) is not differentiable: call it under torch.no_grad(), "
+                                    "or use fast=False to optimise the tree")
             return _RenderPersp.apply(data, self, c2w, width, height, fx, fy, self._opts(False))
         return oops.octree_render_persp(self.tree.view(), c2w, width, height, fx, self._opts(fast), fy)
 

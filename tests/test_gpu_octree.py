@@ -440,10 +440,13 @@ def test_extraction_pipeline_end_to_end(tmp_path):
     # the saved file loads and renders; early-stop and exact renders agree to the thresholds
     loaded = svox.N3Tree.load(out, map_location=dev)
     assert loaded.n_internal == tree.n_internal and torch.equal(loaded.child, tree.child)
-    vid = os.path.join(str(tmp_path), "eval.mp4")
+    vid = os.path.join(str(tmp_path), "eval.gif")
     psnr = evaluation.main(common + ["--input", out, "--renderer_step_size", "1e-3", "--approx_eval_skip", "1",
                                      "--write_vid", vid])
-    assert np.isfinite(psnr) and os.path.exists(os.path.splitext(vid)[0] + ".gif")
+    assert np.isfinite(psnr) and os.path.exists(vid)
+    with pytest.raises(ValueError):        # only GIF output is built (no imageio / ffmpeg): any other extension is refused
+        evaluation.main(common + ["--input", out, "--renderer_step_size", "1e-3", "--approx_eval_skip", "1",
+                                  "--write_vid", os.path.join(str(tmp_path), "eval.mp4")])
     # --z_min / --z_max (extraction.py:91-100, :298-301): grid planes outside the world-z range never enter the tree, the
     # rest of the mask is untouched; the reference's command line spelling (--is_jaxnerf_ckpt etc.) parses
     tz = extraction.main(common + ["--output", os.path.join(str(tmp_path), "tree_z.npz"), "--init_grid_depth", "4",
@@ -502,8 +505,12 @@ def test_octree_full_size_properties():
     diff = (im_rays - im).abs()
     assert float((diff > 2e-5).float().mean()) < 5e-3 and float(diff.max()) < 0.05 and float(diff.mean()) < 2e-6, (
         float((diff > 2e-5).float().mean()), float(diff.max()), float(diff.mean()))
-    fast = r.render_persp(c2w, width=W, height=H, fx=focal, fast=True)
+    with torch.no_grad():
+        fast = r.render_persp(c2w, width=W, height=H, fx=focal, fast=True)
     assert float((fast - im).abs().max()) < 0.03                              # sigma/stop thresholds of 1e-2
+    if tree.data.requires_grad:       # the early-stopping preset is not differentiable: loud, not a detached image
+        with pytest.raises(oops.PxoError):
+            r.render_persp(c2w, width=W, height=H, fx=focal, fast=True)
     # gradient: linear in grad_out, confined to leaves that rays reached
     g1, g2 = torch.randn(H, W, 3, device=dev, generator=g), torch.randn(H, W, 3, device=dev, generator=g)
     opts = r._opts(False)

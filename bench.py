@@ -45,6 +45,8 @@ def parse(argv=None):
     p.add_argument("--force-dist", action="store_true",
                    help="initialise RCCL and issue the per-step collectives even with one rank (exercises the "
                         "multi-GPU code path on a 1-GPU box)")
+    p.add_argument("--no-kernel-events", action="store_true",
+                   help="A/B only: no HIP events around the dominant kernels in the timed region (no roofline leg)")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
     p.add_argument("--cpu-steps", type=int, default=8)
     return p.parse_args(argv)
@@ -229,7 +231,7 @@ def run_train(job, preset, steps, warmup):
     for s in range(warmup):
         one_step(s)
     job.sync()
-    ops.profile_enable(True)
+    ops.profile_enable(not getattr(a, "no_kernel_events", False))
     t0 = time.perf_counter()
     for s in range(warmup, warmup + steps):
         one_step(s)

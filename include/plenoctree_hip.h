@@ -150,6 +150,18 @@ int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float
                             const float* d_comp_rgb, int64_t B, int S, float* d_raw_rgb,
                             float* d_raw_sigma, void* stream);
 
+/* The two above and the pixel loss between them (nerf_sh/train.py:89-98: mean((rgb - pixels)^2) over B*3, whose
+ * gradient 2 (rgb - pixels) / (3B) seeds the reverse pass) in ONE launch -- what pxo_train_fwd_bwd runs per pass.
+ * Outputs: ray_sse [B] = sum_c (rgb_c - pixel_c)^2 per ray, d_raw_rgb [(B*S + n_sp),3K], d_raw_sigma [B*S + n_sp];
+ * comp_rgb [B,3] and weights [B,S] may be NULL.  n_sp > 0: rows B*S .. B*S+n_sp-1 of raw_sigma are the sparsity
+ * points of train.py:77-85 (loss_sp = w (1 - mean(exp(-len relu(sigma))))): their sigma gradient is written, their
+ * rgb gradient zeroed, and sp_exp [n_sp] receives exp(-len relu(sigma)) per point. */
+int pxo_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma,
+                              const float* z_vals, const float* directions, const float* viewdirs,
+                              const float* pixels, int64_t B, int S, float* comp_rgb, float* weights,
+                              float* ray_sse, float* d_raw_rgb, float* d_raw_sigma, int64_t n_sp,
+                              float* sp_exp, void* stream);
+
 /* sample_pdf (piecewise_constant_pdf + sort + cast_rays), nerf_sh/nerf/model_utils.py:225-314
  * with bins/weights derived as in nerf_sh/nerf/models.py:296-301.
  * z_coarse, w_coarse [B,Nc]; u [B,Nf] in [0,1) or NULL (randomized=False).
@@ -188,6 +200,14 @@ int pxo_mean_over_samples(const PxoCfg* cfg, const float* raw_rgb, const float* 
  * `step` = number of updates already applied. */
 int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t n, float lr,
                   int64_t step, float grad_scale, void* stream);
+
+/* The same update of the whole 2-MLP arena AND the refresh of the four fragment-ordered images in one launch
+ * (state.optimizer.apply_gradient + the re-pack that must follow it): equals pxo_adam_step followed by
+ * pxo_pack_weights on both MLPs, bit for bit.  The images must have been written by pxo_pack_weights once (their
+ * zero padding is not rewritten); packed_bwd0/1 may both be NULL.  float32 images only. */
+int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, const float* grads, float lr,
+                       int64_t step, float grad_scale, float* packed_fwd0, float* packed_bwd0,
+                       float* packed_fwd1, float* packed_bwd1, void* stream);
 
 /* ---- whole-path entry points ------------------------------------------------------ */
 

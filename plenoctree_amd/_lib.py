@@ -91,6 +91,7 @@ SIGNATURES = {
     "pxo_mlp_bwd_weights": (c_int, [CFG, P, P, P, P, P, P, c_int64, P, P, c_size_t, P]),
     "pxo_shade_composite_fwd": (c_int, [CFG, P, P, P, P, P, c_int64, c_int, P, P, P, P, P]),
     "pxo_shade_composite_bwd": (c_int, [CFG, P, P, P, P, P, P, c_int64, c_int, P, P, P]),
+    "pxo_shade_composite_train": (c_int, [CFG, P, P, P, P, P, P, c_int64, c_int, P, P, P, P, P, c_int64, P, P]),
     "pxo_sample_pdf": (c_int, [P, P, P, P, c_int64, c_int, c_int, P, P, P, P]),
     "pxo_uniform": (c_int, [c_uint64, c_uint64, c_int64, c_float, c_float, P, P]),
     "pxo_randint": (c_int, [c_uint64, c_uint64, c_int64, c_int64, P, P]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "pxo_generate_rays_multi": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
     "pxo_mean_over_samples": (c_int, [CFG, P, P, c_int64, c_int, P, P]),
     "pxo_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_int64, c_float, P]),
+    "pxo_adam_pack_step": (c_int, [CFG, P, P, P, P, c_float, c_int64, c_float, P, P, P, P, P]),
     "pxo_render_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
     "pxo_render_fwd": (c_int, [CFG, P, P, P, P, P, c_int64, c_int, P, P, c_uint64, P, P, P, P, P, P, P,
                                c_size_t, P]),

@@ -201,22 +201,37 @@ __device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int 
   for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
 }
 
-// B (weights, L2 latency) is fetched kBDist k-groups ahead into four rotating register sets, A (LDS)
-// one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
+// B (weights, L2 latency) is fetched kBDist k-groups ahead into four rotating register sets (the caller's, primed by
+// gemm_prefetch_b), A (LDS) one group ahead into two; kgroups must be a multiple of 4.  No register copies.  The
 // sched_barriers pin "issue next loads, then 16 MFMAs": without them hipcc (at the VGPR cap) sinks
 // each load to just before its use and exposes the LDS/L2 latency on every k-group.
 constexpr int kBDist = 3;   // k-groups of look-ahead for the weight fragments (2 measured 0.25 % slower; four register sets either way)
 #define PXO_PIN() __builtin_amdgcn_sched_barrier(0)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: a wave would wait at every barrier
+// for the acknowledgement of the activation-tile stores it has just issued (and for its prefetched weight fragments);
+// nothing that crosses waves inside these kernels lives in global memory.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// the first kBDist weight fragments of a GEMM (issued by the caller ahead of time, e.g. before the previous layer's
+// epilogue, so that their L2 latency is not exposed when the loop starts)
+template <int CBN>
+__device__ __forceinline__ void gemm_prefetch_b(const f32x4* __restrict__ wp, int kgroups, int kg_stride,
+                                                f32x4 (&b)[4][CBN]) {
+  const int last = kgroups - 1;
+#pragma unroll
+  for (int i = 0; i < kBDist; ++i) load_b<CBN>(wp, i < last ? i : last, kg_stride, b[i]);
+}
+
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
-                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN]) {
+                                                int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN],
+                                                f32x4 (&b)[4][CBN]) {
   constexpr int D = kBDist;
   static_assert(D == 2 || D == 3, "kBDist");
-  f32x4 a0[RBN], a1[RBN], b[4][CBN];
+  f32x4 a0[RBN], a1[RBN];
   const int last = kgroups - 1;
   auto cl = [&](int g) { return g < last ? g : last; };      // harmless re-loads past the end
-#pragma unroll
-  for (int i = 0; i < D; ++i) load_b<CBN>(wp, cl(i), kg_stride, b[i]);
   load_a<RBN>(arow, 0, a0);
   for (int g = 0; g < kgroups; g += 4) {
     // phase p multiplies k-group g+p out of set p and refills set (p+D)%4 with k-group g+p+D
@@ -279,22 +294,30 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RBN][CBN]) {
 // accumulator register `reg` of a 32x32 tile holds row (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// coalesced copy of the finished (32*RBN) x 256 LDS tile to a row-major [M,256] global array (whole 1 KiB
-// rows per wave instruction).  Tried and measured no better: only half of the waves copying while the
-// others start the next GEMM, non-temporal stores, trickling the copy through the next GEMM, and issuing the
-// LDS reads in batches of 8 / 16 ahead of their stores (hipcc alternates read / store; no difference: the cost
-// of this phase is the HBM write path, not the LDS latency).  Removing the copy altogether (PXO_ABLATE_STORE,
-// results wrong) leaves the forward kernel unchanged and speeds the backward(data) kernel up by 6.6 %.
+// Copy of ONE wave's 32 columns of the finished (32*RBN) x 256 LDS tile to a row-major [M,256] global array, by the wave
+// that has just written them (no cross-wave ordering needed: a wave's LDS operations execute in order): per
+// instruction 8 rows x 128 B (whole 128-byte lines).  A workgroup-wide copy of whole 1 KiB rows needs a barrier between
+// the epilogue and the copy; without it the copy is issued right behind the wave's LDS writes and the forward / backward
+// kernels run 1.0 % / 2.9 % faster (round 3 A/B).
 template <int RBN>
-__device__ __forceinline__ void store_tile(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
-                                           int64_t M, bool full, int tid) {
+__device__ __forceinline__ void store_wave_cols(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
+                                                int64_t M, bool full, int wave, int lane) {
+  const int c4 = lane & 7, rsub = lane >> 3;
+  const float* __restrict__ src = lds + rsub * kLDA + wave * 32 + c4 * 4;
+  float* __restrict__ out = dst + (row0 + rsub) * kW + wave * 32 + c4 * 4;
 #pragma unroll
-  for (int i = 0; i < 32 * RBN * kW / 4 / kMlpThreads; ++i) {
-    const int idx = tid + kMlpThreads * i;
-    const int row = idx >> 6, c4 = idx & 63;
-    if (full || row0 + row < M)
-      *reinterpret_cast<f32x4*>(dst + (row0 + row) * kW + c4 * 4) =
-          *reinterpret_cast<const f32x4*>(lds + row * kLDA + c4 * 4);
+  for (int i0 = 0; i0 < 4 * RBN; i0 += 4) {      // four LDS reads in flight per four stores
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (i0 + i) * 8 * kLDA);
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + (int64_t)(i0 + i) * 8 * kW) = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (row0 + (i0 + i) * 8 + rsub < M) *reinterpret_cast<f32x4*>(out + (int64_t)(i0 + i) * 8 * kW) = v[i];
+    }
   }
 }
 
@@ -333,9 +356,9 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
   const bool full = row0 + kRows <= M;
-  __syncthreads();   // previous tile's head GEMM has consumed the LDS tile
+  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile
   posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
-  __syncthreads();
+  lds_barrier();
   if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
 #pragma unroll
     for (int i = 0; i < kRows * kEncPad / 4 / kMlpThreads; ++i) {
@@ -348,22 +371,41 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   }
 
   f32x16 acc[RBN][kCB];
-  for (int l = 0; l < kDepth; ++l) {
-    zero_acc(acc);
-    float bl[kCB];                       // this layer's biases, fetched under the GEMM
+  f32x4 bfrag[4][kCB];
+  auto layer_wp = [&](int l) {
+    return reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
+  };
+  gemm_prefetch_b<kCB>(layer_wp(0), 8, 8 * 64, bfrag);
+  float bl[kCB];                         // the coming layer's biases (this lane's column), fetched one layer ahead
 #pragma unroll
-    for (int c = 0; c < kCB; ++c) bl[c] = bias[l * kW + (wave * kCB + c) * 32 + (lane & 31)];
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
-    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc);
+  for (int c = 0; c < kCB; ++c) bl[c] = bias[(wave * kCB + c) * 32 + (lane & 31)];
+  for (int l = 0; l < kDepth; ++l) {
+    // the accumulators start from the bias (every register of a 32x32 fragment holds this lane's column): the epilogue
+    // saves its 64 adds per wave and layer, which run on the same f32 lanes as the MFMAs
+#pragma unroll
+    for (int r = 0; r < RBN; ++r)
+#pragma unroll
+      for (int c = 0; c < kCB; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][c][i] = bl[c];
+    const f32x4* wp = layer_wp(l);
+    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);
     if (l == 5) {
       // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
       // columns are a second K segment; the encoding is recomputed into the consumed tile.
-      __syncthreads();
+      gemm_prefetch_b<kCB>(wp + (int64_t)32 * 8 * 64, 8, 8 * 64, bfrag);
+      lds_barrier();
       posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
-      __syncthreads();
-      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc);
+      lds_barrier();
+      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc, bfrag);
     }
-    __syncthreads();  // every wave has consumed the input tile
+    // the next GEMM's first weight fragments (and biases) travel while this wave is in its epilogue
+    if (l + 1 < kDepth) {
+      gemm_prefetch_b<kCB>(layer_wp(l + 1), 32, 8 * 64, bfrag);
+#pragma unroll
+      for (int c = 0; c < kCB; ++c) bl[c] = bias[(l + 1) * kW + (wave * kCB + c) * 32 + (lane & 31)];
+    }
+    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite
     // re-derive the lane ids from an opaque copy so that the epilogue / store addresses are
     // computed here instead of being hoisted out of the loops into (scarce) registers
     int tid_e = tid;
@@ -377,11 +419,10 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 #pragma unroll
       for (int c = 0; c < kCB; ++c) {
         const int col = (wave * kCB + c) * 32 + (lane_e & 31);
-        const float b = bl[c];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = r * 32 + frag_row(reg, lane_e);
-          const float v = fmaxf(acc[r][c][reg] + b, 0.f);
+          const float v = fmaxf(acc[r][c][reg], 0.f);
           lds[row * kLDA + col] = v;
           if (SAVE) mask_push(mw[((r * kCB + c) * 16 + reg) >> 5], v);
         }
@@ -390,9 +431,10 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
       uint32_t* mp = mask + ((slot * kDepth + l) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
       for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];
+      // this wave's 32 columns leave for HBM right behind its LDS writes (no barrier in between)
+      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, wave, lane_e);
     }
-    __syncthreads();
-    if (SAVE) store_tile<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, tid_e);
+    lds_barrier();
   }
 
   // heads: [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b (model_utils.py:72-74, :91-93);
@@ -416,13 +458,23 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
       gemm_head<1>(ar, wp, 0, NHB * 64, hacc);
       const int col = cb * 32 + (lane & 31);
       const float b = hb[col];
+      // one destination per lane (its head column), chosen once: the 16 stores below are then straight-line code (per-
+      // element branches made hipcc wait for every store before the next one)
+      float* __restrict__ dst = nullptr;
+      int64_t stride = 0;
+      if (col < C) { if (RGB) { dst = raw_rgb + col; stride = C; } }
+      else if (col == C) { dst = raw_sigma; stride = 1; }
+      if (dst) {
+        const int64_t r0 = row0 + rb * 32 + 4 * (lane >> 5);
+        if (full) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t grow = row0 + rb * 32 + frag_row(reg, lane);
-        if (grow < M) {
-          const float v = hacc[0][0][reg] + b;
-          if (col < C) { if (RGB) raw_rgb[grow * C + col] = v; }
-          else if (col == C) raw_sigma[grow] = v;
+          for (int reg = 0; reg < 16; ++reg) dst[(r0 + (reg & 3) + 8 * (reg >> 2)) * stride] = hacc[0][0][reg] + b;
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int64_t grow = r0 + (reg & 3) + 8 * (reg >> 2);
+            if (grow < M) dst[grow * stride] = hacc[0][0][reg] + b;
+          }
         }
       }
     }
@@ -523,7 +575,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   const int C = rgb_channels(deg);
   const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
   const bool full = row0 + kRows <= M;
-  __syncthreads();   // previous tile's stores out of LDS are done
+  lds_barrier();   // previous tile's stores out of LDS are done
   // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
   for (int idx = tid; idx < kRows * NH; idx += kMlpThreads) {
     const int row = idx / NH, col = idx - row * NH;
@@ -535,7 +587,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
     }
     lds[row * kLDA + col] = v;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < NH) {  // head bias gradient
     float sum = 0.f;
 #pragma unroll 8
@@ -544,6 +596,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   }
 
   f32x16 acc[RBN][kCB];
+  f32x4 bfrag[4][kCB];
   zero_acc(acc);
   uint32_t mw[kMaskWords];   // relu-mask words of the layer whose gradient the running GEMM produces
   {
@@ -551,10 +604,14 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];
     const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
-    gemm_lds_packed<RBN, kCB>(arow, wp, 4 * NHB, 8 * 64, acc);
+    gemm_prefetch_b<kCB>(wp, 4 * NHB, 8 * 64, bfrag);
+    gemm_lds_packed<RBN, kCB>(arow, wp, 4 * NHB, 8 * 64, acc, bfrag);
   }
   for (int l = kDepth - 1; l >= 0; --l) {
-    __syncthreads();  // previous GEMM (and tile copy) has consumed the tile
+    // the next GEMM's first weight fragments travel while this wave is in its epilogue
+    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l > 0 ? l : 1, deg)) + (wave * kCB) * 64 + lane;
+    if (l > 0) gemm_prefetch_b<kCB>(wp, 32, 8 * 64, bfrag);
+    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));   // see fwd_tile: keeps the epilogue addresses out of the loops' live set
     const int lane_e = tid_e & 63;
@@ -574,18 +631,14 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
       colsum += __shfl_xor(colsum, 32);
       if (lane_e < 32) my_db[l * kW + col] += colsum;
     }
-    __syncthreads();
-    if (l > 0) {
-      zero_acc(acc);
-      const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
+    store_wave_cols<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, full, wave, lane_e);
+    lds_barrier();
+    if (l == 0) break;
+    zero_acc(acc);
+    const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
-      for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
-      const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l, deg)) + (wave * kCB) * 64 + lane;
-      store_tile<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, full, tid_e);
-      gemm_lds_packed<RBN, kCB>(arow, wp, 32, 8 * 64, acc);
-    } else {
-      store_tile<RBN>(lds, dz, row0, M, full, tid_e);
-    }
+    for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
+    gemm_lds_packed<RBN, kCB>(arow, wp, 32, 8 * 64, acc, bfrag);
   }
 }
 
@@ -606,7 +659,7 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
     bwd_tile<NHB, kRB / 2>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, ts.half_row0 + h * (kTM / 2),
                            ts.n_full + h, dz, tid, lane, wave);
-  __syncthreads();
+  lds_barrier();
   // one partial per workgroup: [wg][9][256]
   float* out = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
   for (int i = tid; i < 9 * kW; i += kMlpThreads) out[i] = my_db[i];

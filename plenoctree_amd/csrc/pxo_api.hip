@@ -75,6 +75,38 @@ KernelTimer::~KernelTimer() {
   if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
 }
 
+// Side stream of pxo_train_fwd_bwd: the parameter norm (weight_l2) depends on the parameters only and is issued beside
+// the forward pass, between a fork event on the caller's stream and a join back into it.  Created on first use for
+// the current device (one process drives one GPU), never destroyed.
+struct SideStreams {
+  static constexpr int kN = 1;
+  hipStream_t s[kN] = {nullptr};
+  hipEvent_t fork[1] = {}, join[1][kN] = {};
+  bool ok = false;
+};
+static SideStreams& side_streams() {
+  static SideStreams ss;
+  if (!ss.ok) {
+    bool good = true;
+    for (int i = 0; i < SideStreams::kN; ++i) good = good && hipStreamCreateWithFlags(&ss.s[i], hipStreamNonBlocking) == hipSuccess;
+    for (int f = 0; f < 1; ++f) {
+      good = good && hipEventCreateWithFlags(&ss.fork[f], hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < SideStreams::kN; ++i)
+        good = good && hipEventCreateWithFlags(&ss.join[f][i], hipEventDisableTiming) == hipSuccess;
+    }
+    ss.ok = good;
+  }
+  return ss;
+}
+// fork point `f`: side stream i may start once everything issued so far on `main` is done
+static bool fork_to(SideStreams& ss, int f, hipStream_t main, int i) {
+  return hipEventRecord(ss.fork[f], main) == hipSuccess && hipStreamWaitEvent(ss.s[i], ss.fork[f], 0) == hipSuccess;
+}
+// join: `main` waits for everything issued so far on side stream i
+static bool join_from(SideStreams& ss, int f, hipStream_t main, int i) {
+  return hipEventRecord(ss.join[f][i], ss.s[i]) == hipSuccess && hipStreamWaitEvent(main, ss.join[f][i], 0) == hipSuccess;
+}
+
 // bump allocator over the caller's workspace; with base == nullptr it only measures
 struct Carver {
   char* base;
@@ -94,7 +126,7 @@ struct PassBuffers {      // one MLP pass (coarse or fine)
   int S = 0;              // samples per ray
   float *z, *pts, *raw_rgb, *raw_sigma, *acts, *enc, *comp_rgb, *disp, *acc, *weights;
   uint32_t* mask;
-  float *d_comp, *d_raw_rgb, *d_raw_sigma, *dz, *dbias;
+  float *ray_sse, *d_raw_rgb, *d_raw_sigma, *dz, *dbias;
 };
 
 static void carve_pass(Carver& c, PassBuffers& p, int64_t B, int S, int64_t extra_rows, int C, bool train,
@@ -115,20 +147,20 @@ static void carve_pass(Carver& c, PassBuffers& p, int64_t B, int S, int64_t extr
     p.acts = c.take<float>(p.M * kW * kDepth);
     p.enc = c.take<float>(p.M * kEncPad);
     p.mask = c.take<uint32_t>(mask_words(p.M));
-    p.d_comp = c.take<float>(B * 3);
+    p.ray_sse = c.take<float>(B);
     p.d_raw_rgb = c.take<float>(p.M * C);
     p.d_raw_sigma = c.take<float>(p.M);
     p.dz = c.take<float>(p.M * kW * kDepth);
     p.dbias = c.take<float>(dbias_floats(p.M));
   } else {
-    p.acts = p.enc = p.d_comp = p.d_raw_rgb = p.d_raw_sigma = p.dz = p.dbias = nullptr;
+    p.acts = p.enc = p.ray_sse = p.d_raw_rgb = p.d_raw_sigma = p.dz = p.dbias = nullptr;
     p.mask = nullptr;
   }
 }
 
 struct TrainWs {
   PassBuffers c, f;
-  float *t_rand, *u, *sp, *scalars;
+  float *t_rand, *u, *sp, *scalars, *sp_exp;
   void* wgrad_ws;
   size_t wgrad_bytes;
   int64_t n_sp;
@@ -149,6 +181,7 @@ static void carve_train(const PxoCfg* cfg, int64_t B, void* ws, bool train, Trai
   t.u = c.take<float>(B * (Nf > 0 ? Nf : 1));
   t.sp = c.take<float>(t.n_sp * 3 + 4);
   t.scalars = c.take<float>(128);
+  t.sp_exp = c.take<float>(t.n_sp + 4);
   if (train) {
     const int64_t Mmax = Nf > 0 ? t.f.M : t.c.M;
     t.wgrad_bytes = wgrad_workspace_bytes(cfg, Mmax);
@@ -166,23 +199,22 @@ static void carve_train(const PxoCfg* cfg, int64_t B, void* ws, bool train, Trai
     if (_rc != PXO_OK) return _rc; \
   } while (0)
 
-// forward of NerfModel.__call__ into the pass buffers; returns via p the intermediate tensors
+// forward of NerfModel.__call__ into the pass buffers.  pixels != nullptr selects the training form: compositing,
+// the pixel loss and its reverse in one kernel per pass (d_raw_* and ray_sse are written, the rgb/disp/acc outputs are
+// not), with the sparsity rows of the last pass served by the same launch.
 static int run_forward(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* pk1, const float* o,
                        const float* d, const float* v, int64_t B, int randomized, const float* t_rand,
-                       const float* u, const float* sp_points, uint64_t seed, bool train, float* rgb_c,
+                       const float* u, const float* sp_points, uint64_t seed, const float* pixels, float* rgb_c,
                        float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f, hipStream_t s) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
-  if (randomized && !t_rand) {
-    PXO_TRY(launch_uniform(seed, 0, B * Nc, 0.f, 1.f, t.t_rand, s));
-    t_rand = t.t_rand;
-  }
-  if (!randomized) t_rand = nullptr;
-  if (randomized && Nf > 0 && !u) {
-    PXO_TRY(launch_uniform(seed, 1, B * Nf, 0.f, 1.f, t.u, s));
-    u = t.u;
-  }
-  if (!randomized) u = nullptr;
+  const bool train = pixels != nullptr;
   PassBuffers& last = Nf > 0 ? t.f : t.c;
+  // every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
+  UniformJob jobs[3];
+  int nj = 0;
+  if (randomized && !t_rand) { jobs[nj++] = UniformJob{0, B * Nc, 0.f, 1.f, t.t_rand}; t_rand = t.t_rand; }
+  if (randomized && Nf > 0 && !u) { jobs[nj++] = UniformJob{1, B * Nf, 0.f, 1.f, t.u}; u = t.u; }
+  if (!randomized) { t_rand = nullptr; u = nullptr; }
   if (t.n_sp > 0) {
     float* dst = last.pts + B * last.S * 3;
     if (sp_points) {
@@ -191,21 +223,30 @@ static int run_forward(const PxoCfg* cfg, TrainWs& t, const float* pk0, const fl
         return PXO_ERR_HIP;
       }
     } else {
-      PXO_TRY(launch_uniform(seed, 2, t.n_sp * 3, -cfg->sparsity_radius, cfg->sparsity_radius, dst, s));
+      jobs[nj++] = UniformJob{2, t.n_sp * 3, -cfg->sparsity_radius, cfg->sparsity_radius, dst};
     }
   }
+  PXO_TRY(launch_uniform_jobs(seed, jobs, nj, s));
   // coarse pass
   PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, t_rand, t.c.z, t.c.pts, s));
   PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s));
-  PXO_TRY(launch_shade_composite_fwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, B, Nc, rgb_c, disp_c, acc_c,
-                                     t.c.weights, s));
+  if (train)
+    PXO_TRY(launch_shade_composite_train(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, pixels, B, Nc, nullptr,
+                                         Nf > 0 ? t.c.weights : nullptr, t.c.ray_sse, t.c.d_raw_rgb, t.c.d_raw_sigma,
+                                         Nf > 0 ? 0 : t.n_sp, t.sp_exp, s));
+  else
+    PXO_TRY(launch_shade_composite_fwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, B, Nc, rgb_c, disp_c, acc_c,
+                                       t.c.weights, s));
   if (Nf > 0) {
     PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, u, t.f.z, t.f.pts, s));
     PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
-    PXO_TRY(launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f,
-                                       acc_f, t.f.weights, s));
+    if (train)
+      PXO_TRY(launch_shade_composite_train(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, pixels, B, Nc + Nf, nullptr,
+                                           nullptr, t.f.ray_sse, t.f.d_raw_rgb, t.f.d_raw_sigma, t.n_sp, t.sp_exp, s));
+    else
+      PXO_TRY(launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f,
+                                         acc_f, t.f.weights, s));
   }
-  (void)train;
   return PXO_OK;
 }
 
@@ -324,6 +365,19 @@ int pxo_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const float
                                     d_raw_rgb, d_raw_sigma, (hipStream_t)stream);
 }
 
+int pxo_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z_vals,
+                              const float* directions, const float* viewdirs, const float* pixels, int64_t B, int S,
+                              float* comp_rgb, float* weights, float* ray_sse, float* d_raw_rgb, float* d_raw_sigma,
+                              int64_t n_sp, float* sp_exp, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  if (B == 0) return PXO_OK;
+  PXO_REQUIRE(B >= 0 && n_sp >= 0 && raw_rgb && raw_sigma && z_vals && directions && viewdirs && pixels && ray_sse &&
+                  d_raw_rgb && d_raw_sigma && (n_sp == 0 || sp_exp),
+              "pxo_shade_composite_train: bad arguments");
+  return launch_shade_composite_train(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, pixels, B, S, comp_rgb,
+                                      weights, ray_sse, d_raw_rgb, d_raw_sigma, n_sp, sp_exp, (hipStream_t)stream);
+}
+
 int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* origins, const float* directions,
                    int64_t B, int Nc, int Nf, const float* u, float* z_out, float* pts, void* stream) {
   if (B == 0) return PXO_OK;
@@ -402,7 +456,7 @@ int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* pac
     return PXO_ERR_WORKSPACE;
   }
   return run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
-                     nullptr, seed, false, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, (hipStream_t)stream);
+                     nullptr, seed, nullptr, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, (hipStream_t)stream);
 }
 
 int pxo_train_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes) {
@@ -436,28 +490,17 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
     set_error("pxo_train_fwd_bwd: workspace %zu < %zu", ws_bytes, t.total);
     return PXO_ERR_WORKSPACE;
   }
-  const int deg = cfg->sh_deg, C = rgb_channels(deg);
+  const int deg = cfg->sh_deg;
   const int64_t n_mlp = mlp_param_count(deg);
+  SideStreams& ss = side_streams();
+  if (!ss.ok) { set_error("pxo_train_fwd_bwd: could not create the side streams"); return PXO_ERR_HIP; }
+  // weight_l2 = sum(p^2) / n (train.py:101-108) depends on the parameters only: its partial sums run beside the forward pass
+  float* const sumsq_partial = t.scalars;
+  if (!fork_to(ss, 0, s, 0)) { set_error("pxo_train_fwd_bwd: stream fork failed"); return PXO_ERR_HIP; }
+  PXO_TRY(launch_sumsq_partials(params, 2 * n_mlp, sumsq_partial, ss.s[0]));
+  // forward, losses (train.py:77-98) and the reverse of the compositing
   PXO_TRY(run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
-                      sp_points, seed, true, t.c.comp_rgb, t.c.disp, t.c.acc, Nf > 0 ? t.f.comp_rgb : nullptr,
-                      Nf > 0 ? t.f.disp : nullptr, Nf > 0 ? t.f.acc : nullptr, s));
-  // scalars: [0] sse_f, [1] sse_c, [2] sum_exp, [3..] sumsq (+scratch)
-  float* sc = t.scalars;
-  PassBuffers& last = Nf > 0 ? t.f : t.c;
-  // losses (train.py:89-98): fine + coarse MSE
-  PXO_TRY(launch_mse_grad(t.c.comp_rgb, pixels, B, t.c.d_comp, sc + 1, s));
-  if (Nf > 0) PXO_TRY(launch_mse_grad(t.f.comp_rgb, pixels, B, t.f.d_comp, sc + 0, s));
-  PXO_TRY(launch_shade_composite_bwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, directions, viewdirs, t.c.d_comp, B, Nc,
-                                     t.c.d_raw_rgb, t.c.d_raw_sigma, s));
-  if (Nf > 0)
-    PXO_TRY(launch_shade_composite_bwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, directions, viewdirs, t.f.d_comp, B,
-                                       Nc + Nf, t.f.d_raw_rgb, t.f.d_raw_sigma, s));
-  if (t.n_sp > 0) {  // sparsity rows (train.py:77-85): gradient on sigma only
-    const int64_t r0 = B * last.S;
-    PXO_TRY(launch_sparsity_grad(last.raw_sigma + r0, t.n_sp, cfg->sparsity_weight, cfg->sparsity_length,
-                                 last.d_raw_sigma + r0, sc + 2, s));
-    PXO_TRY(launch_fill(last.d_raw_rgb + r0 * C, t.n_sp * C, 0.f, s));
-  }
+                      sp_points, seed, pixels, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   // reverse through the MLPs
   PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, s));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
@@ -471,10 +514,24 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   }
   if (cfg->weight_decay_mult != 0.f)   // + weight_decay_mult * weight_l2 (train.py:101-114)
     PXO_TRY(launch_axpy(grads, params, 2 * n_mlp, 2.f * cfg->weight_decay_mult / (float)(2 * n_mlp), s));
-  PXO_TRY(launch_sumsq(params, 2 * n_mlp, sc + 3, s));
-  PXO_TRY(launch_finalize_stats(sc + 0, sc + 1, sc + 2, sc + 3, B, Nf > 0, t.n_sp, cfg->sparsity_weight, 2 * n_mlp,
-                                stats, s));
+  if (!join_from(ss, 0, s, 0)) { set_error("pxo_train_fwd_bwd: stream join failed"); return PXO_ERR_HIP; }
+  PXO_TRY(launch_finalize_stats(Nf > 0 ? t.f.ray_sse : nullptr, t.c.ray_sse, t.n_sp > 0 ? t.sp_exp : nullptr, sumsq_partial,
+                                B, t.n_sp, cfg->sparsity_weight, 2 * n_mlp, stats, s));
   return PXO_OK;
+}
+
+int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, const float* grads, float lr, int64_t step,
+                       float grad_scale, float* packed_fwd0, float* packed_bwd0, float* packed_fwd1, float* packed_bwd1,
+                       void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(params && m && v && grads && step >= 0 && packed_fwd0 && packed_fwd1, "pxo_adam_pack_step: bad arguments");
+  PXO_REQUIRE((packed_bwd0 != nullptr) == (packed_bwd1 != nullptr), "pxo_adam_pack_step: both backward images or none");
+  if (cfg->mlp_precision != PXO_MLP_F32) {
+    set_error("pxo_adam_pack_step: the split-precision images are inference-only (use pxo_adam_step + pxo_pack_weights)");
+    return PXO_ERR_UNSUPPORTED;
+  }
+  return launch_adam_pack(cfg, params, m, v, grads, lr, step, grad_scale, packed_fwd0, packed_bwd0, packed_fwd1,
+                          packed_bwd1, (hipStream_t)stream);
 }
 
 int pxo_profile_enable(int on) {

@@ -182,16 +182,20 @@ int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float
                    hipStream_t s);
 int launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, int64_t step,
                 float grad_scale, hipStream_t s);
-// d_rgb = 2*(rgb-px)/(3B); partial[0] = sum((rgb-px)^2) (deterministic single-block reduce)
-int launch_mse_grad(const float* rgb, const float* pixels, int64_t B, float* d_rgb, float* sse_out,
-                    hipStream_t s);
-// sparsity branch (train.py:77-85): d_raw_sigma for the appended rows + sum(exp(-len*relu(s)))
-int launch_sparsity_grad(const float* raw_sigma, int64_t n, float weight, float length,
-                         float* d_raw_sigma, float* sum_exp_out, hipStream_t s);
-int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);
-int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* sum_exp,
-                          const float* sumsq, int64_t B, int has_fine, int64_t n_sp, float sp_weight,
-                          int64_t n_params, float* stats, hipStream_t s);
+// training form of the compositing: forward + pixel loss + reverse in one launch (see render_kernels.hip); serves the
+// n_sp sparsity rows appended to the pass as well
+int launch_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z,
+                                 const float* dirs, const float* viewdirs, const float* pixels, int64_t B, int S,
+                                 float* comp_rgb, float* weights, float* ray_sse, float* d_raw_rgb, float* d_raw_sigma,
+                                 int64_t n_sp, float* sp_exp, hipStream_t s);
+// up to 3 uniform draws (Philox streams of one seed) in one launch
+struct UniformJob { uint64_t stream_id; int64_t n; float lo, hi; float* out; };
+int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s);
+int launch_sumsq_partials(const float* x, int64_t n, float* partial, hipStream_t s);   // 64 partial sums
+int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* sp_exp, const float* sumsq_partial,
+                          int64_t B, int64_t n_sp, float sp_weight, int64_t n_params, float* stats, hipStream_t s);
+int launch_adam_pack(const PxoCfg* cfg, float* p, float* m, float* v, const float* g, float lr, int64_t step,
+                     float grad_scale, float* fwd0, float* bwd0, float* fwd1, float* bwd1, hipStream_t s);
 int launch_fill(float* p, int64_t n, float v, hipStream_t s);
 int launch_axpy(float* y, const float* x, int64_t n, float a, hipStream_t s);
 

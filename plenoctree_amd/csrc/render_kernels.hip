@@ -244,6 +244,106 @@ __global__ __launch_bounds__(kRayThreads) void shade_composite_bwd_kernel(
   }
 }
 
+// Training form: forward compositing, the pixel loss of nerf_sh/train.py:89-98 and the reverse pass in ONE launch (the
+// backward kernel above already re-derives the whole forward state in registers; the loss gradient of a ray depends on
+// that ray's colour only).  Per ray: comp_rgb (+weights for sample_pdf), sse[ray] = sum_c (comp_c - px_c)^2 (summed
+// in a fixed order by finalize_stats), d_comp = 2 (comp - px) / (3 B), then d_raw_rgb / d_raw_sigma as above.
+// Blocks past the rays serve the sparsity rows appended to the pass (train.py:77-85): e = exp(-len relu(s)),
+// d_raw_sigma = w len e / n for s > 0, and a zero gradient on their raw_rgb.
+template <int DEG>
+__global__ __launch_bounds__(kRayThreads) void shade_composite_train_kernel(
+    const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma, const float* __restrict__ z_vals,
+    const float* __restrict__ dirs, const float* __restrict__ viewdirs, const float* __restrict__ pixels, int64_t B,
+    int S, int white, float* __restrict__ comp_rgb, float* __restrict__ weights, float* __restrict__ ray_sse,
+    float* __restrict__ d_raw_rgb, float* __restrict__ d_raw_sigma, int64_t n_sp, float sp_weight, float sp_length,
+    float* __restrict__ sp_exp) {
+  constexpr int K = (DEG + 1) * (DEG + 1), C = 3 * K, CS = C | 1;
+  __shared__ float lds[kRaysPerBlock][64 * CS];
+  const int64_t ray_blocks = (B + kRaysPerBlock - 1) / kRaysPerBlock;
+  if ((int64_t)blockIdx.x >= ray_blocks) {       // sparsity rows [B*S, B*S + n_sp)
+    const int64_t r0 = ((int64_t)blockIdx.x - ray_blocks) * kRayThreads;
+    const int64_t row = r0 + threadIdx.x;
+    const int64_t base = B * S;
+    if (row < n_sp) {
+      const float raw = raw_sigma[base + row];
+      const float e = expf(-sp_length * fmaxf(raw, 0.f));
+      sp_exp[row] = e;
+      d_raw_sigma[base + row] = raw > 0.f ? (sp_weight * sp_length / (float)n_sp) * e : 0.f;
+    }
+    const int64_t nrow = n_sp - r0 < kRayThreads ? n_sp - r0 : kRayThreads;
+    float* __restrict__ z0 = d_raw_rgb + (base + r0) * C;
+    for (int64_t i = threadIdx.x; i < nrow * C; i += kRayThreads) z0[i] = 0.f;
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t ray = blockIdx.x * (int64_t)kRaysPerBlock + wave;
+  const bool ray_ok = ray < B;
+  if (!ray_ok) ray = B - 1;
+  float Y[K];
+  sh_basis<DEG>(viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], Y);
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float norm_d = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float bgc = white ? 1.f : 0.f;
+  const int nch = (S + 63) / 64;
+  SampleState st[kMaxChunks];
+  float carry = 1.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_acc = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < kMaxChunks; ++ch)
+    if (ch < nch) {
+      shade_chunk<DEG>(raw_rgb, raw_sigma, z_vals, lds[wave], Y, ray, S, ch, lane, norm_d, carry, st[ch]);
+      const float w = (1.f - st[ch].e) * st[ch].T;
+      s_r += w * st[ch].rgb[0]; s_g += w * st[ch].rgb[1]; s_b += w * st[ch].rgb[2]; s_acc += w;
+      if (weights && ray_ok && ch * 64 + lane < S) weights[ray * S + ch * 64 + lane] = w;
+    }
+  s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b); s_acc = wave_sum(s_acc);
+  const float bg = white ? 1.f - s_acc : 0.f;
+  const float c0 = s_r + bg, c1 = s_g + bg, c2 = s_b + bg;
+  const float e0 = c0 - pixels[ray * 3], e1 = c1 - pixels[ray * 3 + 1], e2 = c2 - pixels[ray * 3 + 2];
+  const float scale = 2.f / (float)(B * 3);
+  const float g0 = e0 * scale, g1 = e1 * scale, g2 = e2 * scale;
+  if (ray_ok && lane == 0) {
+    ray_sse[ray] = (e0 * e0 + e1 * e1) + e2 * e2;
+    if (comp_rgb) { comp_rgb[ray * 3] = c0; comp_rgb[ray * 3 + 1] = c1; comp_rgb[ray * 3 + 2] = c2; }
+  }
+  float suffix = 0.f;  // sum over later samples of dL/dw_j * w_j
+#pragma unroll
+  for (int ch = kMaxChunks - 1; ch >= 0; --ch) {
+    if (ch >= nch) continue;
+    const SampleState& q = st[ch];
+    const bool valid = ch * 64 + lane < S;
+    const float alpha = 1.f - q.e;
+    const float w = alpha * q.T;
+    const float dw = g0 * (q.rgb[0] - bgc) + g1 * (q.rgb[1] - bgc) + g2 * (q.rgb[2] - bgc);
+    const float G = valid ? dw * w : 0.f;
+    const float incl = wave_rscan_add(G, lane);
+    float excl = __shfl_down(incl, 1);
+    if (lane == 63) excl = 0.f;
+    const float R = suffix + excl;
+    suffix += __shfl(incl, 0);
+    const float fct = (1.f - alpha) + 1e-10f;
+    const float dalpha = dw * q.T - R / fct;
+    const float dsigma = dalpha * q.dist * q.e;
+    const int64_t base = ray * S + ch * 64;
+    if (ray_ok && valid) d_raw_sigma[base + lane] = q.raw_sigma > 0.f ? dsigma : 0.f;
+    __syncthreads();
+    if (valid) {
+      const float dp[3] = {g0 * w * q.rgb[0] * (1.f - q.rgb[0]), g1 * w * q.rgb[1] * (1.f - q.rgb[1]),
+                           g2 * w * q.rgb[2] * (1.f - q.rgb[2])};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave][lane * CS + c * K + k] = dp[c] * Y[k];
+    }
+    __syncthreads();
+    const int nvalid = S - ch * 64 < 64 ? S - ch * 64 : 64;
+    if (ray_ok)
+      for (int idx = lane; idx < nvalid * C; idx += 64) {
+        const int s = idx / C, j = idx - s * C;
+        d_raw_rgb[base * C + idx] = lds[wave][s * CS + j];
+      }
+  }
+}
+
 #define PXO_DEG_SWITCH(deg, CALL) \
   switch (deg) {                  \
     case 0: CALL(0); break;       \
@@ -277,6 +377,22 @@ int launch_shade_composite_bwd(const PxoCfg* cfg, const float* raw_rgb, const fl
   PXO_DEG_SWITCH(cfg->sh_deg, CALL)
 #undef CALL
   return check_launch("shade_composite_bwd");
+}
+
+int launch_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z,
+                                 const float* dirs, const float* viewdirs, const float* pixels, int64_t B, int S,
+                                 float* comp_rgb, float* weights, float* ray_sse, float* d_raw_rgb, float* d_raw_sigma,
+                                 int64_t n_sp, float* sp_exp, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  if (S > 64 * kMaxChunks || S < 1) { set_error("samples per ray %d not in [1,%d]", S, 64 * kMaxChunks); return PXO_ERR_ARG; }
+  const int64_t blocks = (B + kRaysPerBlock - 1) / kRaysPerBlock + (n_sp + kRayThreads - 1) / kRayThreads;
+  dim3 grid((unsigned)blocks), block(kRayThreads);
+#define CALL(D) hipLaunchKernelGGL((shade_composite_train_kernel<D>), grid, block, 0, s, raw_rgb, raw_sigma, z, dirs, \
+                                   viewdirs, pixels, B, S, cfg->white_bkgd, comp_rgb, weights, ray_sse, d_raw_rgb,       \
+                                   d_raw_sigma, n_sp, cfg->sparsity_weight, cfg->sparsity_length, sp_exp)
+  PXO_DEG_SWITCH(cfg->sh_deg, CALL)
+#undef CALL
+  return check_launch("shade_composite_train");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,11 +582,15 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
 }
 
-__global__ void uniform_kernel(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi,
-                               float* __restrict__ out) {
+struct UniformJobs { UniformJob job[3]; };
+
+// blockIdx.y selects the job; element idx of a job is word idx % 4 of the Philox block with counter idx / 4 and the
+// job's stream id in the upper counter words
+__global__ void uniform_kernel(uint64_t seed, UniformJobs J) {
+  const UniformJob& jb = J.job[blockIdx.y];
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (q * 4 >= n) return;
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  if (q * 4 >= jb.n) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)jb.stream_id, (uint32_t)(jb.stream_id >> 32)};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -480,9 +600,9 @@ __global__ void uniform_kernel(uint64_t seed, uint64_t stream_id, int64_t n, flo
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t idx = q * 4 + i;
-    if (idx < n) {
+    if (idx < jb.n) {
       const float r01 = (float)(c[i] >> 8) * (1.0f / 16777216.0f);   // [0,1), 24 bits
-      out[idx] = lo + (hi - lo) * r01;
+      jb.out[idx] = jb.lo + (jb.hi - jb.lo) * r01;
     }
   }
 }
@@ -514,11 +634,25 @@ int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, 
   return check_launch("randint");
 }
 
-int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, hipStream_t s) {
-  if (n == 0) return PXO_OK;
-  const int64_t q = (n + 3) / 4;
-  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, seed, stream_id, n, lo, hi, out);
+int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s) {
+  UniformJobs J;
+  int64_t qmax = 0;
+  int nj = 0;
+  for (int i = 0; i < n_jobs && nj < 3; ++i) {
+    if (jobs[i].n <= 0) continue;
+    J.job[nj++] = jobs[i];
+    const int64_t q = (jobs[i].n + 3) / 4;
+    if (q > qmax) qmax = q;
+  }
+  if (nj == 0) return PXO_OK;
+  for (int i = nj; i < 3; ++i) J.job[i] = UniformJob{0, 0, 0.f, 0.f, nullptr};
+  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((qmax + 255) / 256), nj), dim3(256), 0, s, seed, J);
   return check_launch("uniform");
+}
+
+int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, hipStream_t s) {
+  const UniformJob job{stream_id, n, lo, hi, out};
+  return launch_uniform_jobs(seed, &job, 1, s);
 }
 
 }  // namespace pxo

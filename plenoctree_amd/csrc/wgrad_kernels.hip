@@ -329,7 +329,9 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
     return PXO_ERR_WORKSPACE;
   }
   // the skinny products (enc-based pair, heads): two workgroups per CU (256 / 128 ranges measured equal or slower at
-  // 4096, 1024 and 512 rays per step)
+  // 4096, 1024 and 512 rays per step).  Issuing them on side streams beside the 256x256 launch was measured too (round 3,
+  // 512 rays per step): 4.05 vs 3.96 ms per step -- the HBM-leaning workgroups take CU slots from the MFMA-bound ones
+  // early and the step gets longer, so the three launches stay in stream order.
   int64_t rpw2; int P2;
   split_rows(M, 2 * (int64_t)num_cus(), &rpw2, &P2);
   const float* h7 = acts + (int64_t)7 * MW;

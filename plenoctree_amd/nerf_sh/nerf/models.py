@@ -143,7 +143,7 @@ def train_step(model, state, batch, lr, randomized=True, t_rand=None, u=None, sp
     if world_size > 1:
         state.stats.mul_(1.0 / world_size)
         scale = 1.0 / world_size
-    ops.adam_step(state.params, state.m, state.v, state.grads, lr, state.step, grad_scale=scale)
+    # Adam (train.py:119) and the refresh of the fragment-ordered weight images, one launch
+    ops.adam_pack_step(cfg, state.params, state.m, state.v, state.grads, lr, state.step, state.packed, grad_scale=scale)
     state.step += 1
-    state.repack()
     return state.stats

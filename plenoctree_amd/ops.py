@@ -205,6 +205,35 @@ def adam_step(params, m, v, grads, lr, step, grad_scale=1.0):
                             float(grad_scale), _stream()), "pxo_adam_step")
 
 
+def adam_pack_step(cfg, params, m, v, grads, lr, step, packed, grad_scale=1.0):
+    """Adam on the whole arena + refresh of the weight images `packed` = [(fwd0, bwd0), (fwd1, bwd1)] in one launch."""
+    _require_gpu()
+    lib = _lib.load()
+    (f0, b0), (f1, b1) = packed
+    check(lib.pxo_adam_pack_step(ctypes.byref(cfg), _f(params), _f(m), _f(v), _f(grads), float(lr), int(step),
+                                 float(grad_scale), _f(f0), _f(b0), _f(f1), _f(b1), _stream()), "pxo_adam_pack_step")
+
+
+def shade_composite_train(cfg, raw_rgb, raw_sigma, z_vals, directions, viewdirs, pixels, n_sp=0, want_rgb=True,
+                          want_weights=True):
+    """Forward compositing + pixel loss + reverse in one launch: returns dict(comp_rgb, weights, ray_sse, d_raw_rgb,
+    d_raw_sigma, sp_exp).  raw_rgb [B*S + n_sp, 3K], raw_sigma [B*S + n_sp]."""
+    _require_gpu()
+    lib = _lib.load()
+    B, S = z_vals.shape
+    C = raw_rgb.shape[-1]
+    dev = raw_rgb.device
+    out = {"comp_rgb": _new(B, 3, device=dev) if want_rgb else None,
+           "weights": _new(B, S, device=dev) if want_weights else None,
+           "ray_sse": _new(B, device=dev), "d_raw_rgb": _new(B * S + n_sp, C, device=dev),
+           "d_raw_sigma": _new(B * S + n_sp, device=dev), "sp_exp": _new(max(n_sp, 1), device=dev)}
+    check(lib.pxo_shade_composite_train(ctypes.byref(cfg), _f(raw_rgb), _f(raw_sigma), _f(z_vals), _f(directions),
+                                        _f(viewdirs), _f(pixels), B, S, _f(out["comp_rgb"]), _f(out["weights"]),
+                                        _f(out["ray_sse"]), _f(out["d_raw_rgb"]), _f(out["d_raw_sigma"]), n_sp,
+                                        _f(out["sp_exp"]), _stream()), "pxo_shade_composite_train")
+    return out
+
+
 def render_workspace_bytes(cfg, B):
     n = ctypes.c_size_t(0)
     check(_lib.load().pxo_render_workspace_bytes(ctypes.byref(cfg), B, ctypes.byref(n)), "pxo_render_workspace_bytes")

@@ -15,7 +15,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     # steady state: whole steps only -- from the end of the 5th-last Adam launch to the end of the last one
-    ends = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+    ends = [i for i, r in enumerate(rows) if "adam" in r[2]]
     if len(ends) >= 5:
         rows = rows[ends[-5] + 1: ends[-1] + 1]
         print(f"window: the last 4 training steps ({(rows[-1][1] - rows[0][0]) / 4e6:.3f} ms per step incl. the feeder)")

@@ -24,7 +24,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+    ends = [i for i, r in enumerate(rows) if "adam" in r[2]]
     if len(ends) < n_steps + 1:
         raise SystemExit("not enough adam launches to delimit steps")
     # a step = (end of the previous step's last pack kernel ...]: delimit at adam launches

@@ -116,19 +116,20 @@ int main() {
   hipMemcpy(w, h.data(), 8 * 65536 * 4, hipMemcpyHostToDevice);
   hipMemcpy(in, h.data() + 8 * 65536, 8192 * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int v = 0; v < 4; ++v) {
-    float ms = 0; int blocks = v == 1 ? 256 : 512; int rows = v == 1 ? 128 : 64;
+  for (int v = 0; v < 5; ++v) {
+    float ms = 0; int blocks = (v == 1 || v == 4) ? 256 : 512; int rows = (v == 1 || v == 4) ? 128 : 64;
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL((gemm_regs<2, 2, 4, 64>), dim3(512), dim3(256), 0, 0, w, in, out, layers);
       if (v == 1) hipLaunchKernelGGL((gemm_regs<4, 1, 8, 128>), dim3(256), dim3(512), 0, 0, w, in, out, layers);
       if (v == 2) hipLaunchKernelGGL((gemm_dma<4>), dim3(512), dim3(256), 0, 0, w, in, out, layers);
       if (v == 3) hipLaunchKernelGGL((gemm_dma<3>), dim3(512), dim3(256), 0, 0, w, in, out, layers);
+      if (v == 4) hipLaunchKernelGGL((gemm_regs<4, 1, 4, 128>), dim3(256), dim3(256), 0, 0, w, in, out, layers);   // ONE wave per SIMD
       hipEventRecord(e1); hipEventSynchronize(e1);
       hipEventElapsedTime(&ms, e0, e1);
     }
-    double flop = (double)blocks * rows * 256.0 * 256.0 * 2.0 * layers;
-    const char* names[] = {"G0 64x64/wave 4w 2WG/CU B->VGPR", "G1 128x32/wave 8w 1WG/CU B->VGPR", "G2 G0 + B via LDS-DMA ring4", "G3 G0 + B via LDS-DMA ring3"};
+    double flop = (double)blocks * rows * 256.0 * (v == 4 ? 128.0 : 256.0) * 2.0 * layers;
+    const char* names[] = {"G0 64x64/wave 4w 2WG/CU B->VGPR", "G1 128x32/wave 8w 1WG/CU B->VGPR", "G2 G0 + B via LDS-DMA ring4", "G3 G0 + B via LDS-DMA ring3", "G4 128x32/wave 4w (one wave per SIMD) 1WG/CU B->VGPR"};
     printf("%s: %.3f ms  %.1f TFLOP/s (%.1f%%)  err=%s\n", names[v], ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
   }
   return 0;

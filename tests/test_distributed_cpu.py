@@ -67,9 +67,13 @@ def _patch_ops(cfg):
         p, m2, v2 = O.adam_update(params, m, v, grads * grad_scale, lr, step)
         params.copy_(p); m.copy_(m2); v.copy_(v2)
 
+    def adam_pack_step(pcfg, params, m, v, grads, lr, step, packed, grad_scale=1.0):
+        adam_step(params, m, v, grads, lr, step, grad_scale)     # the stand-in images alias the parameters
+
     ops.pack_weights = pack_weights
     ops.train_fwd_bwd = train_fwd_bwd
     ops.adam_step = adam_step
+    ops.adam_pack_step = adam_pack_step
     ops.train_workspace_bytes = lambda pcfg, B: 16
     ops.render_workspace_bytes = lambda pcfg, B: 16
 
@@ -128,8 +132,10 @@ def _worker(rank, world, port, outdir):
     rgb, disp, acc = utils.render_image(render_fn, img_rays, chunk=16, world_size=comm.world, rank=comm.rank,
                                         gather=comm.all_gather_cat)
     # voxel-sharded grid evaluation + gather (octree/extraction.py step 1)
-    sig = extraction.grid_sigma(model, state, 5, [0, 0, 0], [1.5, 1.5, 1.5], comm)
-    torch.save({"params": state.params, "stats": state.stats, "rgb": rgb, "disp": disp, "acc": acc, "sig": sig},
+    sig = extraction.grid_sigma(model, state, 5, [0, 0, 0], [1.5, 1.5, 1.5], comm)       # ragged slabs (3 + 2 planes)
+    sig6 = extraction.grid_sigma(model, state, 6, [0, 0, 0], [1.5, 1.5, 1.5], comm)      # equal slabs: gathered in place
+    torch.save({"params": state.params, "stats": state.stats, "rgb": rgb, "disp": disp, "acc": acc, "sig": sig,
+                "sig6": sig6},
                os.path.join(outdir, f"rank{rank}.pt"))
     comm.barrier()
     comm.shutdown()
@@ -165,11 +171,11 @@ def test_two_rank_data_parallel_matches_single_process():
         assert torch.allclose(r["rgb"], rgb) and torch.allclose(r["disp"][..., 0], (o * 2 + d)[..., 0] * 3)
         assert torch.allclose(r["acc"][..., 0], (o * 2 + d)[..., 2])
     # sharded grid == full grid, on every rank
-    reso = 5
-    ix, iy, iz = torch.meshgrid(*[torch.arange(reso, dtype=torch.float32)] * 3, indexing="ij")
-    full = (ix * 10000 + iy * 100 + iz).reshape(-1)
-    for r in res:
-        assert torch.equal(r["sig"], full)
+    for reso, key in ((5, "sig"), (6, "sig6")):
+        ix, iy, iz = torch.meshgrid(*[torch.arange(reso, dtype=torch.float32)] * 3, indexing="ij")
+        full = (ix * 10000 + iy * 100 + iz).reshape(-1)
+        for r in res:
+            assert torch.equal(r[key], full)
 
 
 def test_slab_range_partitions_grid():

@@ -290,6 +290,81 @@ def test_shade_composite_fwd_bwd(deg, S, white, opaque):
     close("d_raw_sigma", d_sigma, rs.grad.reshape(-1), rtol=2e-4, atol=1e-6 * max(1.0, float(rs.grad.abs().max())))
 
 
+@pytest.mark.parametrize("deg,S,white,n_sp", [(3, 64, True, 0), (3, 192, True, 1000), (4, 192, True, 257), (1, 40, False, 3)])
+def test_shade_composite_train_fused(deg, S, white, n_sp):
+    """The one-launch training form (compositing + pixel loss + reverse + sparsity rows) against the loss of
+    nerf_sh/train.py:77-98 differentiated by autograd on the oracle, and against the separate fwd / bwd kernels."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg, white_bkgd=white, sparsity_length=0.07, sparsity_weight=2e-3)
+    pcfg = pxo_cfg(ops, cfg)
+    B = 41
+    C = cfg.num_rgb_channels
+    rays, raw_rgb, raw_sigma, z = _composite_inputs(B, S, C, 29 + S, False)
+    gen = torch.Generator().manual_seed(5)
+    px = torch.rand(B, 3, generator=gen)
+    sp_sigma = torch.randn(n_sp, generator=gen) * 20
+    all_rgb = torch.cat([raw_rgb.reshape(B * S, C), torch.randn(n_sp, C, generator=gen)])
+    all_sigma = torch.cat([raw_sigma.reshape(-1), sp_sigma])
+    out = ops.shade_composite_train(pcfg, all_rgb.to(dev), all_sigma.to(dev), z.to(dev), rays.directions.to(dev),
+                                    rays.viewdirs.to(dev), px.to(dev), n_sp=n_sp)
+    rr = raw_rgb.clone().requires_grad_(True)
+    rs = raw_sigma.clone().requires_grad_(True)
+    sps = sp_sigma.clone().requires_grad_(True)
+    c_ref, _, _, w_ref = _oracle_composite(cfg, rays, rr, rs, z)
+    loss = ((c_ref - px) ** 2).mean()                                                   # train.py:89
+    if n_sp:
+        loss = loss + cfg.sparsity_weight * (1.0 - torch.exp(-cfg.sparsity_length * torch.relu(sps)).mean())   # :81-83
+    loss.backward()
+    close("comp_rgb", out["comp_rgb"], c_ref, rtol=1e-5, atol=2e-6)
+    close("weights", out["weights"], w_ref, rtol=1e-4, atol=2e-6)
+    close("ray_sse", out["ray_sse"], ((c_ref - px) ** 2).sum(-1), rtol=1e-4, atol=1e-7)
+    close("d_raw_rgb", out["d_raw_rgb"][:B * S], rr.grad.reshape(B * S, -1), rtol=1e-4, atol=1e-8)
+    close("d_raw_sigma", out["d_raw_sigma"][:B * S], rs.grad.reshape(-1), rtol=2e-4,
+          atol=1e-6 * max(1.0, float(rs.grad.abs().max())))
+    if n_sp:
+        close("sparsity d_raw_sigma", out["d_raw_sigma"][B * S:], sps.grad, rtol=1e-5, atol=1e-12)
+        close("sparsity exp", out["sp_exp"][:n_sp], torch.exp(-cfg.sparsity_length * torch.relu(sp_sigma)), rtol=1e-6, atol=1e-7)
+        assert bool((out["d_raw_rgb"][B * S:] == 0).all())
+    # identical to the stage kernels fed the same loss gradient
+    args = (all_rgb[:B * S].to(dev), all_sigma[:B * S].to(dev), z.to(dev), rays.directions.to(dev), rays.viewdirs.to(dev))
+    comp, _, _, w = ops.shade_composite_fwd(pcfg, *args)
+    # (the compiler contracts multiply-adds differently in the two kernels: equal to float32 round-off, not bitwise)
+    close("fused vs staged comp_rgb", out["comp_rgb"], comp, rtol=1e-6, atol=1e-7)
+    close("fused vs staged weights", out["weights"], w, rtol=1e-6, atol=1e-9)
+    d_rgb, d_sigma = ops.shade_composite_bwd(pcfg, *args, (comp - px.to(dev)) * (2.0 / (3 * B)))
+    close("fused vs staged d_raw_rgb", out["d_raw_rgb"][:B * S], d_rgb, rtol=1e-5, atol=1e-10)
+    close("fused vs staged d_raw_sigma", out["d_raw_sigma"][:B * S], d_sigma, rtol=1e-5,
+          atol=1e-6 * max(1.0, float(d_sigma.abs().max())))
+
+
+@pytest.mark.parametrize("deg", [3, 4])
+def test_adam_pack_step_equals_adam_then_pack(deg):
+    """pxo_adam_pack_step == pxo_adam_step followed by pxo_pack_weights on both MLPs, bit for bit (parameters,
+    moments and all four fragment-ordered images, zero padding included)."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg); pcfg = pxo_cfg(ops, cfg)
+    gen = torch.Generator().manual_seed(77 + deg)
+    flat = make_params(cfg, bias_scale=0.2)
+    n = flat.numel() // 2
+    pa, pb = flat.to(dev), flat.to(dev)
+    ma = torch.rand(2 * n, generator=gen).to(dev) * 1e-3; mb = ma.clone()
+    va = torch.rand(2 * n, generator=gen).to(dev) * 1e-6; vb = va.clone()
+    packed = [ops.pack_weights(pcfg, split_mlp(pa, cfg, i)) for i in range(2)]
+    for step in range(2):
+        g = (torch.randn(2 * n, generator=gen) * 1e-2).to(dev)
+        ops.adam_pack_step(pcfg, pa, ma, va, g, 3e-4, step, packed, grad_scale=0.5)
+        ops.adam_step(pb, mb, vb, g, 3e-4, step, grad_scale=0.5)
+    report = {name: (int((a != b).sum()), float((a - b).abs().max())) for name, a, b in
+              (("params", pa, pb), ("m", ma, mb), ("v", va, vb))}
+    assert all(n == 0 for n, _ in report.values()), f"adam_pack_step vs adam_step (count differing, max abs): {report}"
+    assert not torch.equal(pa.cpu(), flat)
+    for i in range(2):
+        f_ref, b_ref = ops.pack_weights(pcfg, split_mlp(pb, cfg, i))
+        for name, a, b in ((f"forward image of MLP_{i}", packed[i][0], f_ref), (f"backward image of MLP_{i}", packed[i][1], b_ref)):
+            bad = (a != b).nonzero().reshape(-1)
+            assert bad.numel() == 0, f"{name}: {bad.numel()} of {a.numel()} differ, first at {bad[:5].tolist()}"
+
+
 def test_composite_known_answers():
     ops = _ops(); dev = _gpu()
     cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)

@@ -395,7 +395,20 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
       // columns are a second K segment; the encoding is recomputed into the consumed tile.
       gemm_prefetch_b<kCB>(wp + (int64_t)32 * 8 * 64, 8, 8 * 64, bfrag);
       lds_barrier();
-      posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+      if (SAVE) {
+        // training: every thread reads back the 16-byte pieces of the encoded tile it stored itself at the start of the
+        // tile (L2-resident), ~20 instructions instead of 16 sinf evaluations on the lanes the MFMAs run on
+#pragma unroll
+        for (int i = 0; i < kRows * kEncPad / 4 / kMlpThreads; ++i) {
+          const int idx = tid + kMlpThreads * i;
+          const int row = idx >> 4, c4 = idx & 15;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (full || row0 + row < M) v = *reinterpret_cast<const f32x4*>(enc_out + (row0 + row) * kEncPad + c4 * 4);
+          *reinterpret_cast<f32x4*>(lds + row * kLDA + c4 * 4) = v;
+        }
+      } else {
+        posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+      }
       lds_barrier();
       gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc, bfrag);
     }

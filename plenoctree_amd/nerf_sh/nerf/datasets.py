@@ -28,6 +28,24 @@ def pose_spherical(theta_deg, phi_deg, radius):
     return c2w
 
 
+def area_resize(image, out_h, out_w):
+    """cv2.resize(image, (out_w, out_h), interpolation=cv2.INTER_AREA) for down-scaling a float [H,W,C] image (cv2 is
+    not installed): every output pixel is the area-weighted mean of the source pixels its footprint [j s, (j+1) s)
+    covers, s = in / out, separable.  For an integer factor on a divisible size (the reference's factor = 2 on the
+    800 x 800 Blender images, nerf_sh/nerf/datasets.py:208-212) this is exactly the mean of factor x factor blocks."""
+    def weights(n_in, n_out):
+        s = n_in / n_out
+        w = np.zeros((n_out, n_in), np.float64)
+        for j in range(n_out):
+            lo, hi = j * s, (j + 1) * s
+            for i in range(int(np.floor(lo)), min(int(np.ceil(hi)), n_in)):
+                w[j, i] = max(0.0, min(hi, i + 1) - max(lo, i)) / s
+        return w
+    img = np.asarray(image, np.float32)
+    wy, wx = weights(img.shape[0], out_h), weights(img.shape[1], out_w)
+    return np.einsum("yi,ijc,xj->yxc", wy, img.astype(np.float64), wx).astype(np.float32)
+
+
 def analytic_scene_rgb(origins, directions, white_bkgd=True):
     """Colour seen along each ray: three hard spheres with view-dependent shading."""
     o, d = origins.double(), directions.double()
@@ -197,10 +215,11 @@ class Blender(Dataset):
         images, cams = [], []
         for frame in meta["frames"]:
             fname = os.path.join(args.data_dir, frame["file_path"] + ".png")
-            img = Image.open(fname)
-            if args.factor >= 2:
-                img = img.resize((img.width // args.factor, img.height // args.factor), Image.BOX)  # area filter
-            image = np.asarray(img, dtype=np.float32) / 255.0
+            image = np.asarray(Image.open(fname), dtype=np.float32) / 255.0
+            if args.factor == 2:            # datasets.py:208-212: the float RGBA image, before compositing
+                image = area_resize(image, image.shape[0] // 2, image.shape[1] // 2)
+            elif args.factor > 0:           # :213-216
+                raise ValueError(f"Blender dataset only supports factor=0 or 2, {args.factor} set.")
             cams.append(np.array(frame["transform_matrix"], dtype=np.float32))
             images.append(image)
         images = np.stack(images, 0)
@@ -240,13 +259,12 @@ class NSVF(Dataset):
         cam_trans = np.diag(np.array([1, -1, -1, 1], dtype=np.float32))       # OpenCV -> OpenGL axes (:517)
         images, cams = [], []
         for img_name, pose_name in zip(img_files, pose_files):
-            img = Image.open(os.path.join(root, "rgb", img_name))
-            if args.factor > 1:
-                img = img.resize((img.width // args.factor, img.height // args.factor), Image.BOX)  # area filter
-            image = np.asarray(img, dtype=np.float32) / 255.0
+            image = np.asarray(Image.open(os.path.join(root, "rgb", img_name)), dtype=np.float32) / 255.0
             cams.append(np.loadtxt(os.path.join(root, "pose", pose_name)) @ cam_trans)
             if image.shape[-1] == 4:
                 image = image[..., :3] * image[..., -1:] + (1.0 - image[..., -1:]) if self.white_bkgd else image[..., :3]
+            if args.factor > 1:             # :430-434: after compositing, any integer factor
+                image = area_resize(image, image.shape[0] // args.factor, image.shape[1] // args.factor)
             images.append(image)
         images = np.stack(images, 0)
         self.n_examples, self.h, self.w = images.shape[:3]

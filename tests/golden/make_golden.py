@@ -98,6 +98,16 @@ def main():
     for name in ("DEFINE_string", "DEFINE_integer", "DEFINE_float", "DEFINE_bool", "DEFINE_enum", "DEFINE_boolean"):
         setattr(flags, name, lambda *a, **k: None)
     absl.flags = flags
+
+    def cv2_resize(image, size, interpolation=None):
+        """cv2.resize(..., INTER_AREA) for the exact integer down-scalings the fixtures use: on a divisible size the
+        area filter IS the mean over factor x factor blocks (float32 accumulation order aside)."""
+        ow, oh = size
+        h, w = image.shape[:2]
+        assert interpolation == "INTER_AREA" and h % oh == 0 and w % ow == 0 and h // oh == w // ow
+        f = h // oh
+        return image.reshape(oh, f, ow, f, -1).astype(np.float64).mean(axis=(1, 3)).astype(np.float32)
+    cv2.resize, cv2.INTER_AREA = cv2_resize, "INTER_AREA"
     sys.modules.update({"absl": absl, "absl.flags": flags, "cv2": cv2})
     from octree.nerf import utils as ref_utils             # noqa: E402
     from octree.nerf import datasets as ref_datasets       # noqa: E402
@@ -127,6 +137,13 @@ def main():
                 out[f"{kind}_{split}_images"] = np.asarray(ds.images, np.float32).reshape(ds.size, ds.h, ds.w, 3)
                 out[f"{kind}_{split}_camtoworlds"] = np.asarray(ds.camtoworlds, np.float32)
                 out[f"{kind}_{split}_hwf"] = np.array([ds.h, ds.w, ds.focal], np.float64)
+        # factor = 2 (the only non-zero factor the reference's Blender loader accepts, datasets.py:100-109; NSVF: :430-444)
+        for kind, root, cls in (("blender", broot, ref_datasets.Blender), ("nsvf", nroot, ref_datasets.NSVF)):
+            args = types.SimpleNamespace(data_dir=root, white_bkgd=True, factor=2, render_path=False,
+                                         batch_size=4, image_batching=False)
+            ds = cls("train", args)
+            out[f"{kind}_train_f2_images"] = np.asarray(ds.images, np.float32).reshape(ds.size, ds.h, ds.w, 3)
+            out[f"{kind}_train_f2_hwf"] = np.array([ds.h, ds.w, ds.focal], np.float64)
     np.savez_compressed(os.path.join(HERE, "loaders.npz"), **out)
 
     # ---- nerf_sh/nerf/model_utils.py through a numpy-backed jax shim ----------

@@ -107,6 +107,20 @@ def test_loaders_match_the_reference_loaders(golden_dir, tmp_path):
             np.testing.assert_allclose(ds.camtoworlds, g[f"{kind}_{split}_camtoworlds"], rtol=1e-6, atol=1e-7)
             imgs = ds.images.reshape(ds.size, ds.h, ds.w, 3).numpy()
             np.testing.assert_allclose(imgs, g[f"{kind}_{split}_images"], rtol=0, atol=1e-6)
+        # factor = 2: cv2.INTER_AREA at an exact 2x down-scaling is the mean of 2x2 blocks; the fixture was produced by
+        # the reference's loader with that definition standing in for cv2.resize (cv2 is not installed anywhere here)
+        a = utils.define_flags().parse_args(["--train_dir", "x", "--data_dir", root, "--dataset", kind])
+        a.factor, a.white_bkgd = 2, True
+        ds = datasets.get_dataset("train", a, torch.device("cpu"), batch_size=4)
+        h, w, focal = g[f"{kind}_train_f2_hwf"]
+        assert (ds.h, ds.w) == (int(h), int(w)) and ds.focal == pytest.approx(float(focal), rel=1e-6)
+        np.testing.assert_allclose(ds.images.reshape(ds.size, ds.h, ds.w, 3).numpy(), g[f"{kind}_train_f2_images"],
+                                   rtol=0, atol=1e-6)
+    # the reference's Blender loader raises for any other factor (nerf_sh/nerf/datasets.py:213-216)
+    a = utils.define_flags().parse_args(["--train_dir", "x", "--data_dir", roots["blender"], "--dataset", "blender"])
+    a.factor, a.white_bkgd = 4, True
+    with pytest.raises(ValueError):
+        datasets.get_dataset("train", a, torch.device("cpu"), batch_size=4)
 
 
 def test_sampling_compositing_pdf_match_the_reference_function_bodies(golden_dir):

@@ -211,22 +211,32 @@ def read_kernels(ops, deg):
     return kernels
 
 
-def run_train(job, preset, steps, warmup):
-    """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats."""
+EVAL_STEP = 105      # render_fwd / grid512 are evaluated on the parameters after exactly this many train steps
+
+
+def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None):
+    """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats.
+    snapshot_step: a copy of the parameters after exactly that many steps from the fixed-seed initialisation is kept
+    (taken inside the run if it gets that far, by untimed extra steps otherwise), so that the records evaluated on
+    "a trained-ish network" do not depend on --steps / --warmup."""
     from plenoctree_amd import ops
     from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
     a = job.a
-    per_gpu = a.batch if a.scaling == "weak" else a.batch // job.world
+    if per_gpu is None:
+        per_gpu = a.batch if a.scaling == "weak" else a.batch // job.world
     args = flags_for(preset, per_gpu)
     model, params = models.construct_nerf(args, job.device)
     state = models.TrainState(model.cfg, params)
     dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
+    snap = {}
 
     def one_step(step):
         batch = next(dataset)
         lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps)
         models.train_step(model, state, batch, lr, randomized=True, seed=(step << 8) | job.rank,
                           world_size=job.world, all_reduce=job.all_reduce_sum if job.dist else None)
+        if state.step == snapshot_step:
+            snap["params"] = state.params.clone()          # 4 MB device copy
 
     for s in range(warmup):
         one_step(s)
@@ -243,7 +253,45 @@ def run_train(job, preset, steps, warmup):
     out = {"elapsed": elapsed, "per_gpu": per_gpu, "deg": deg, "kernels": read_kernels(ops, deg),
            "stats": dict(zip(utils.Stats._fields, state.stats.cpu().tolist())), "args": args,
            "model": model, "state": state, "dataset": dataset}
+    if snapshot_step is not None:
+        for s in range(state.step, snapshot_step):          # untimed: a short run did not get there
+            one_step(s)
+        out["eval_state"] = models.TrainState(model.cfg, snap["params"])
+        out["eval_step"] = snapshot_step
     return out
+
+
+def run_strong512(job, a):
+    """The strong-scaling shape of BASELINE configs[2]: the reference's global batch of 4096 rays over 8 GPUs = 512
+    rays per GPU per step (train.py:117-118: one pmean per step).  Measured on this job's GPUs with 512 rays each and
+    the per-step collective issued through RCCL even with one rank (the gradient arena + stats, one all-reduce), so
+    the number is what one GPU of an 8-GPU strong-scaling run does before the wire time of that all-reduce."""
+    import torch.distributed as dist_mod
+    own_group = False
+    if job.dist is None:
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29533 + os.getpid() % 2000))
+            dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=job.device)
+            job.dist, own_group = dist_mod, True
+        except Exception as e:                       # the record then says so instead of failing the bench
+            own_group = None
+            err = repr(e)[:200]
+    k = max(40, a.steps)
+    t = run_train(job, a.preset, k, 5, per_gpu=512)
+    rec = {"value": 512 * job.world * k / t["elapsed"], "unit": "rays/s", "rays_per_gpu": 512, "steps": k,
+           "ms_per_step": 1e3 * t["elapsed"] / k, "collectives_per_step": 1 if job.dist else 0,
+           "frac": 512 * k / t["elapsed"] * FLOP_TRAIN_PER_RAY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12),
+           "kernels": [{"kernel": e["kernel"], "avg_ms": e["avg_ms"], "tflops": e.get("tflops")} for e in t["kernels"]],
+           "note": "per-GPU work of the 8-GPU strong-scaling run of the reference's 4096-ray batch; 10k sparsity points "
+                   "per GPU per step (train.py:78-80) are not counted as rays"}
+    if own_group:
+        job.sync()
+        dist_mod.destroy_process_group()
+        job.dist = None
+    elif own_group is None:
+        rec["rccl_init_error"] = err
+    return rec
 
 
 def split_precision_twin(tr):
@@ -253,7 +301,7 @@ def split_precision_twin(tr):
     cfg.mlp_precision = 1
     twin = dict(tr)
     twin["model"] = models.NerfModel(cfg)
-    twin["state"] = models.TrainState(cfg, tr["state"].params.clone())
+    twin["eval_state"] = models.TrainState(cfg, tr["eval_state"].params.clone())
     return twin
 
 
@@ -261,7 +309,7 @@ def run_render(job, tr, iters=20):
     """The eval path (nerf_sh/eval.py -> utils.render_image): pxo_render_fwd on `batch` rays per GPU per call,
     deterministic sampling (eval.py:57)."""
     from plenoctree_amd import ops
-    model, state = tr["model"], tr["state"]
+    model, state = tr["model"], tr["eval_state"]
     batch = next(tr["dataset"])
     rays = batch["rays"]
     for _ in range(2):
@@ -277,7 +325,7 @@ def run_render(job, tr, iters=20):
     read_kernels(ops, tr["deg"])          # drain the event records
     rps = tr["per_gpu"] * job.world * iters / elapsed
     return {"value": rps, "unit": "rays/s", "calls": iters, "rays_per_call_per_gpu": tr["per_gpu"],
-            "ms_per_call": 1e3 * elapsed / iters,
+            "ms_per_call": 1e3 * elapsed / iters, "params_after_steps": tr["eval_step"],
             "frac": rps / job.world * FLOP_RENDER_PER_RAY[tr["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
 
 
@@ -288,7 +336,7 @@ def run_grid512(job, tr, stages_after_grid=True):
     from plenoctree_amd import octree_ops as oops
     from plenoctree_amd.octree import extraction
     from plenoctree_amd.octree.svox import N3Tree
-    model, state, dataset = tr["model"], tr["state"], tr["dataset"]
+    model, state, dataset = tr["model"], tr["eval_state"], tr["dataset"]
     comm = job.comm()
     reso, center, radius = 512, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5]
     if model.cfg.mlp_precision == 0:
@@ -320,10 +368,12 @@ def run_grid512(job, tr, stages_after_grid=True):
     t_tree = job.max_over_ranks(time.perf_counter() - t0)
     n_pts = reso ** 3
     tflops = n_pts * FLOP_SIGMA_PER_POINT / t_grid / 1e12
+    weight_voxels, mask_voxels = int((weights >= 1e-3).sum()), int(mask.sum())     # weight_thresh default, extraction.py:126-132
     del weights, mask, sig
-    return {"points": n_pts, "grid_ms": 1e3 * t_grid, "tflops": tflops,
+    return {"points": n_pts, "params_after_steps": tr["eval_step"], "grid_ms": 1e3 * t_grid, "tflops": tflops,
             "frac": tflops / job.world / PEAK_F32_MFMA_TFLOPS, "weight_mask_ms": 1e3 * t_weight,
-            "weight_mask_views": int(dataset.size), "tree_build_ms": 1e3 * t_tree,
+            "weight_mask_views": int(dataset.size), "weight_mask_voxels": weight_voxels,
+            "tree_build_ms": 1e3 * t_tree, "tree_mask_voxels": mask_voxels,
             "tree_nodes": int(tree.n_internal), "sharding": f"x-slabs over {job.world} GPU(s) + all-gather"}
 
 
@@ -345,9 +395,10 @@ def main():
     if job.dist:
         job.dist.barrier()
 
-    tr = run_train(job, a.preset, a.steps, a.warmup)
+    tr = run_train(job, a.preset, a.steps, a.warmup, snapshot_step=None if a.no_extras else EVAL_STEP)
     extras = {}
     if not a.no_extras:
+        extras["strong512"] = run_strong512(job, a)
         extras["render_fwd"] = run_render(job, tr)
         extras["grid512"] = run_grid512(job, tr)
         # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
@@ -360,7 +411,7 @@ def main():
             "grid512_ms": g3["grid_ms"], "grid512_equivalent_f32_tflops": g3["equivalent_f32_tflops"]}
         twin = None
         other = "tt" if a.preset == "blender" else "blender"
-        tr["state"] = tr["dataset"] = None          # release the headline workspace before the second preset
+        tr["state"] = tr["eval_state"] = tr["dataset"] = None   # release the headline workspace before the second preset
         torch.cuda.empty_cache()
         k2 = max(10, a.steps // 4)
         t2 = run_train(job, other, k2, 3)

@@ -90,13 +90,21 @@ def test_render_fwd_full_batch(preset, randomized):
             d_f32=abs(p_hip - p32), d_f64=abs(p_hip - p64), oracle_s=t_cpu)
     assert abs(p_hip - p32) <= 1e-4 and abs(p_hip - p64) <= 1e-4, (p_hip, p32, p64)
     assert abs(p_hip_c - p64_c) <= 1e-4
-    # and the image itself: PSNR of HIP against the float64 render >= 70 dB (rms 3e-4; measured 76-85 dB -- the
-    # residual sits in the few pixels whose fine samples fall into nearly empty bins, see test_sample_pdf)
+    # and the image itself, arbitrated by the float64 render: the HIP image must be as close to it as the CPU float32
+    # evaluation is (within 3 dB with deterministic sampling, 6 dB with random u: the residual sits in the handful of
+    # pixels whose fine samples fall next to an empty stretch of the cdf, where one ulp of a coarse weight moves a sample
+    # by a bin -- each float32 evaluation has its own few), with no pixel off by more than 1e-2 and at most 8 by > 1e-3.
+    # Round 2 measured 76.3 dB here for deterministic sampling against 89.1 dB for the CPU: the float32 cdf of a ray that
+    # ends on a surface plateaus at 1 - 2^-23, which IS the last deterministic u, and `u >= cdf` moved that sample to
+    # the far end of the plateau; sample_pdf_kernel now accumulates the cdf in float64 (93.4 dB, profiles/r03_render_outliers.md).
     err = (out[1][0].cpu().double() - ref64[1][0]).abs().max(dim=-1)[0]
-    _record(f"render_fwd_image[{preset},{randomized}]", psnr_hip_vs_f64=_psnr(out[1][0].cpu(), ref64[1][0]),
-            psnr_f32_vs_f64=_psnr(ref[1][0], ref64[1][0]), max_err=float(err.max()), n_over_1e4=float((err > 1e-4).sum()),
-            n_over_1e3=float((err > 1e-3).sum()), median_err=float(err.median()))
-    assert _psnr(out[1][0].cpu(), ref64[1][0]) >= 70.0
+    p_img_hip, p_img_cpu = _psnr(out[1][0].cpu(), ref64[1][0]), _psnr(ref[1][0], ref64[1][0])
+    _record(f"render_fwd_image[{preset},{randomized}]", psnr_hip_vs_f64=p_img_hip, psnr_f32_vs_f64=p_img_cpu,
+            max_err=float(err.max()), n_over_1e4=float((err > 1e-4).sum()), n_over_1e3=float((err > 1e-3).sum()),
+            median_err=float(err.median()))
+    assert p_img_hip >= p_img_cpu - (6.0 if randomized else 3.0), (p_img_hip, p_img_cpu)
+    assert p_img_hip >= 80.0
+    assert float(err.max()) <= 1e-2 and int((err > 1e-3).sum()) <= 8, (float(err.max()), int((err > 1e-3).sum()))
 
 
 @pytest.mark.parametrize("preset,wd", [("blender", 0.0), ("tt", 0.0), ("blender", 0.1)])

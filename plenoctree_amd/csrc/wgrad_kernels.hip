@@ -73,8 +73,45 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     float zr1[HEAD ? ZV : 1];
     uint32_t okx, okz;           // per-thread validity bits of the rows held in xr / zr4
   };
+  // Whole chunks (every chunk but possibly the last one of the last range) are loaded without row predicates from a
+  // wave-uniform base + a per-thread 32-bit element offset that does not change from chunk to chunk: the address
+  // arithmetic of the inner loop is then scalar (the per-load 64-bit VALU address math and the zero-selects of the
+  // predicated form were 107 VALU instructions per 64 MFMAs -- on the f32 lanes the MFMAs run on).
+  const float* __restrict__ Xb = X + r_begin * KIN;
+  const float* __restrict__ Zb = DUAL ? dZ + r_begin * kW : (HEAD ? dZ : dZ + r_begin * NOUT + ncol0);
+  const float* __restrict__ Zb2 = DUAL ? dZ2 + r_begin * kW : nullptr;
+  uint32_t xoff[XV], zoff[HEAD ? 1 : ZV];
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int idx = tid + NT * i;
+    xoff[i] = (uint32_t)((idx / (KIN / 4)) * KIN + (idx % (KIN / 4)) * 4);
+  }
+  if (!HEAD) {
+#pragma unroll
+    for (int i = 0; i < ZV; ++i) {
+      const int idx = tid + NT * i;
+      const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
+      zoff[i] = DUAL ? (uint32_t)(row * kW + ((c4 * 4) & (kW - 1))) : (uint32_t)(row * NOUT + c4 * 4);
+    }
+  }
   auto load_chunk = [&](int ch, Stage& st) {
     const int64_t r0 = r_begin + (int64_t)ch * KCH;
+    const bool whole = r0 + KCH <= r_end;                   // wave-uniform
+    if (whole) {
+      st.okx = ~0u; st.okz = ~0u;
+      const float* __restrict__ xc = Xb + (int64_t)ch * (KCH * KIN);
+#pragma unroll
+      for (int i = 0; i < XV; ++i) st.xr[i] = *reinterpret_cast<const f32x4*>(xc + xoff[i]);
+      if (!HEAD) {
+        const float* __restrict__ zc = Zb + (int64_t)ch * (KCH * (DUAL ? kW : NOUT));
+        const float* __restrict__ zc2 = DUAL ? Zb2 + (int64_t)ch * (KCH * kW) : nullptr;
+#pragma unroll
+        for (int i = 0; i < ZV; ++i) {
+          const bool second = DUAL && ((tid + NT * i) % (NTILE / 4)) * 4 >= kW;
+          st.zr4[i] = *reinterpret_cast<const f32x4*>((second ? zc2 : zc) + zoff[i]);
+        }
+      }
+    } else {
     st.okx = 0u; st.okz = 0u;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
@@ -85,20 +122,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       st.okx |= (ok ? 1u : 0u) << i;                     // selected at store time, so that nothing
       st.xr[i] = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);  // waits here
     }
-    if (HEAD) {
-#pragma unroll
-      for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + NT * i;
-        const int row = idx / NTILE, col = idx % NTILE;
-        const int64_t grow = r0 + row;
-        float v = 0.f;
-        if (grow < r_end) {
-          if (col < C) v = dZ[grow * C + col];
-          else if (col == C) v = d_raw_sigma[grow];
-        }
-        st.zr1[i] = v;
-      }
-    } else {
+    if (!HEAD) {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
         const int idx = tid + NT * i;
@@ -114,22 +138,47 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
         }
       }
     }
+    }
+    if (HEAD) {
+#pragma unroll
+      for (int i = 0; i < ZV; ++i) {
+        const int idx = tid + NT * i;
+        const int row = idx / NTILE, col = idx % NTILE;
+        const int64_t grow = r0 + row;
+        float v = 0.f;
+        if (grow < r_end) {
+          if (col < C) v = dZ[grow * C + col];
+          else if (col == C) v = d_raw_sigma[grow];
+        }
+        st.zr1[i] = v;
+      }
+    }
   };
   auto store_chunk = [&](int buf, const Stage& st) {
+    if (st.okx == ~0u && st.okz == ~0u) {                     // whole chunk (wave-uniform): no selects
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = tid + NT * i;
-      *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((st.okx >> i) & 1u) ? st.xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(&xs[buf][(tid + NT * i) * 4]) = st.xr[i];
+      if (!HEAD) {
+#pragma unroll
+        for (int i = 0; i < ZV; ++i) *reinterpret_cast<f32x4*>(&zs[buf][(tid + NT * i) * 4]) = st.zr4[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int idx = tid + NT * i;
+        *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((st.okx >> i) & 1u) ? st.xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!HEAD) {
+#pragma unroll
+        for (int i = 0; i < ZV; ++i) {
+          const int idx = tid + NT * i;
+          *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((st.okz >> i) & 1u) ? st.zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
     }
     if (HEAD) {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = st.zr1[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((st.okz >> i) & 1u) ? st.zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
     }
   };
 

@@ -190,15 +190,45 @@ __device__ __forceinline__ void mfma_group(const f32x4 (&a)[RBN], const f32x4 (&
         acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
 }
 
-template <int RBN>
-__device__ __forceinline__ void load_a(const float* __restrict__ arow, int g, f32x4 (&a)[RBN]) {
-#pragma unroll
-  for (int r = 0; r < RBN; ++r) a[r] = *reinterpret_cast<const f32x4*>(arow + r * 32 * kLDA + g * 8);
+// Operand addressing of the k-loop without vector ALU work (measured on the skewed-schedule experiment of round 3:
+// a VALU instruction issued beside a back-to-back stream of v_mfma_f32_32x32x2_f32 waits for the running MFMA and
+// costs the stream ~10 cycles; the loop had 3.5 of them per 16 MFMAs and ran at 95.8 %):
+//  * A: ds_read_b128 takes a 16-bit immediate; row blocks 2-3 sit 66,560 B further on, so they get their own offset
+//    register (ARows::hi) instead of an add per access;
+//  * B: buffer_load_dwordx4 with the weight image as the buffer: the layer / k-group / column-block part of the address
+//    is a wave-uniform byte offset (one SGPR, scalar arithmetic), the lane part one 32-bit register that never changes.
+struct ARows {
+  const float* base;   // the LDS tile
+  uint32_t lo, hi;     // float offsets of this lane's fragment row in row blocks 0-1 (+33,280 B immediate) / 2-3
+};
+__device__ __forceinline__ ARows make_arows(const float* lds, int lane) {
+  ARows a{lds, (uint32_t)((lane & 31) * kLDA + (lane >> 5) * 4), 0u};
+  a.hi = a.lo + 2 * 32 * kLDA;
+  asm volatile("" : "+v"(a.hi));     // an independent induction variable, not "lo + constant" re-derived at every use
+  return a;
 }
-template <int CBN>
-__device__ __forceinline__ void load_b(const f32x4* __restrict__ wp, int g, int kg_stride, f32x4 (&b)[CBN]) {
+template <int RBN>
+__device__ __forceinline__ void load_a(const ARows& ar, int g, f32x4 (&a)[RBN]) {
 #pragma unroll
-  for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * 64];
+  for (int r = 0; r < RBN; ++r)
+    a[r] = *reinterpret_cast<const f32x4*>(ar.base + (r < 2 ? ar.lo : ar.hi) + (r & 1) * 32 * kLDA + g * 8);
+}
+// the packed weight image as a raw buffer: base + wave-uniform byte offset (SGPR) + lane * 16 (VGPR)
+struct WImage {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff;       // lane * 16
+};
+__device__ __forceinline__ WImage make_wimage(const float* image, int64_t floats, int lane) {
+  return WImage{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)(floats * 4), 0x00020000),
+                (uint32_t)lane * 16u};
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// wu: wave-uniform f32x4 index of this wave's first column block of the packed matrix inside the image
+template <int CBN>
+__device__ __forceinline__ void load_b(const WImage& w, int wu, int g, int kg_stride, f32x4 (&b)[CBN]) {
+#pragma unroll
+  for (int c = 0; c < CBN; ++c)
+    b[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, (wu + g * kg_stride + c * 64) * 16, 0));
 }
 
 // B (weights, L2 latency) is fetched kBDist k-groups ahead into four rotating register sets (the caller's, primed by
@@ -216,15 +246,15 @@ __device__ __forceinline__ void lds_barrier() {
 // the first kBDist weight fragments of a GEMM (issued by the caller ahead of time, e.g. before the previous layer's
 // epilogue, so that their L2 latency is not exposed when the loop starts)
 template <int CBN>
-__device__ __forceinline__ void gemm_prefetch_b(const f32x4* __restrict__ wp, int kgroups, int kg_stride,
+__device__ __forceinline__ void gemm_prefetch_b(const WImage& w, int wu, int kgroups, int kg_stride,
                                                 f32x4 (&b)[4][CBN]) {
   const int last = kgroups - 1;
 #pragma unroll
-  for (int i = 0; i < kBDist; ++i) load_b<CBN>(wp, i < last ? i : last, kg_stride, b[i]);
+  for (int i = 0; i < kBDist; ++i) load_b<CBN>(w, wu, i < last ? i : last, kg_stride, b[i]);
 }
 
 template <int RBN, int CBN>
-__device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, const f32x4* __restrict__ wp,
+__device__ __forceinline__ void gemm_lds_packed(const ARows& arow, const WImage& w, int wu,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN],
                                                 f32x4 (&b)[4][CBN]) {
   constexpr int D = kBDist;
@@ -236,22 +266,22 @@ __device__ __forceinline__ void gemm_lds_packed(const float* __restrict__ arow, 
   for (int g = 0; g < kgroups; g += 4) {
     // phase p multiplies k-group g+p out of set p and refills set (p+D)%4 with k-group g+p+D
     load_a<RBN>(arow, g + 1, a1);
-    load_b<CBN>(wp, cl(g + D), kg_stride, b[D & 3]);
+    load_b<CBN>(w, wu, cl(g + D), kg_stride, b[D & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b[0], acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 2, a0);
-    load_b<CBN>(wp, cl(g + 1 + D), kg_stride, b[(1 + D) & 3]);
+    load_b<CBN>(w, wu, cl(g + 1 + D), kg_stride, b[(1 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b[1], acc);
     PXO_PIN();
     load_a<RBN>(arow, g + 3, a1);
-    load_b<CBN>(wp, cl(g + 2 + D), kg_stride, b[(2 + D) & 3]);
+    load_b<CBN>(w, wu, cl(g + 2 + D), kg_stride, b[(2 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b[2], acc);
     PXO_PIN();
     load_a<RBN>(arow, cl(g + 4), a0);
-    load_b<CBN>(wp, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);
+    load_b<CBN>(w, wu, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b[3], acc);
     PXO_PIN();
@@ -267,16 +297,17 @@ __device__ __forceinline__ void gemm_head(const float* __restrict__ arow, const 
 #pragma unroll
     for (int c = 0; c < CBN; ++c) b[c] = wp[(int64_t)g * kg_stride + c * cb_stride];
   };
+  auto la = [&](int g, f32x4 (&a)[1]) { a[0] = *reinterpret_cast<const f32x4*>(arow + g * 8); };
   lb(0, b0); lb(1, b1);
-  load_a<1>(arow, 0, a0);
+  la(0, a0);
   for (int g = 0; g < 32; g += 4) {
-    load_a<1>(arow, g + 1, a1); lb(g + 2, b2); PXO_PIN();
+    la(g + 1, a1); lb(g + 2, b2); PXO_PIN();
     mfma_group<1, CBN>(a0, b0, acc); PXO_PIN();
-    load_a<1>(arow, g + 2, a0); lb(g + 3, b3); PXO_PIN();
+    la(g + 2, a0); lb(g + 3, b3); PXO_PIN();
     mfma_group<1, CBN>(a1, b1, acc); PXO_PIN();
-    load_a<1>(arow, g + 3, a1); lb(g + 4 < 31 ? g + 4 : 31, b0); PXO_PIN();
+    la(g + 3, a1); lb(g + 4 < 31 ? g + 4 : 31, b0); PXO_PIN();
     mfma_group<1, CBN>(a0, b2, acc); PXO_PIN();
-    load_a<1>(arow, g + 4 < 31 ? g + 4 : 31, a0); lb(g + 5 < 31 ? g + 5 : 31, b1); PXO_PIN();
+    la(g + 4 < 31 ? g + 4 : 31, a0); lb(g + 5 < 31 ? g + 5 : 31, b1); PXO_PIN();
     mfma_group<1, CBN>(a1, b3, acc); PXO_PIN();
   }
 }
@@ -354,7 +385,9 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   constexpr int kWordsUsed = RBN * kCB * 16 / 32;     // relu-mask words this tile height fills (of kMaskWords)
   const int C = rgb_channels(deg);
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
-  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
+  const float* arow1 = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
+  const ARows arow = make_arows(lds, lane);
+  const WImage wimg = make_wimage(pk, fwd_image_floats(deg), lane);
   const bool full = row0 + kRows <= M;
   lds_barrier();   // previous tile's head GEMM has consumed the LDS tile
   posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
@@ -372,10 +405,10 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 
   f32x16 acc[RBN][kCB];
   f32x4 bfrag[4][kCB];
-  auto layer_wp = [&](int l) {
-    return reinterpret_cast<const f32x4*>(pk + fwd_layer_off(l)) + (wave * kCB) * 64 + lane;
+  auto layer_wp = [&](int l) {        // wave-uniform f32x4 index into the image
+    return (int)(fwd_layer_off(l) / 4) + (wave * kCB) * 64;
   };
-  gemm_prefetch_b<kCB>(layer_wp(0), 8, 8 * 64, bfrag);
+  gemm_prefetch_b<kCB>(wimg, layer_wp(0), 8, 8 * 64, bfrag);
   float bl[kCB];                         // the coming layer's biases (this lane's column), fetched one layer ahead
 #pragma unroll
   for (int c = 0; c < kCB; ++c) bl[c] = bias[(wave * kCB + c) * 32 + (lane & 31)];
@@ -388,12 +421,12 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
       for (int c = 0; c < kCB; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[r][c][i] = bl[c];
-    const f32x4* wp = layer_wp(l);
-    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);
+    const int wp = layer_wp(l);
+    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);
     if (l == 5) {
       // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
       // columns are a second K segment; the encoding is recomputed into the consumed tile.
-      gemm_prefetch_b<kCB>(wp + (int64_t)32 * 8 * 64, 8, 8 * 64, bfrag);
+      gemm_prefetch_b<kCB>(wimg, wp + 32 * 8 * 64, 8, 8 * 64, bfrag);
       lds_barrier();
       if (SAVE) {
         // training: every thread reads back the 16-byte pieces of the encoded tile it stored itself at the start of the
@@ -410,11 +443,11 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
         posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
       }
       lds_barrier();
-      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc, bfrag);
+      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);
     }
     // the next GEMM's first weight fragments (and biases) travel while this wave is in its epilogue
     if (l + 1 < kDepth) {
-      gemm_prefetch_b<kCB>(layer_wp(l + 1), 32, 8 * 64, bfrag);
+      gemm_prefetch_b<kCB>(wimg, layer_wp(l + 1), 32, 8 * 64, bfrag);
 #pragma unroll
       for (int c = 0; c < kCB; ++c) bl[c] = bias[(l + 1) * kW + (wave * kCB + c) * 32 + (lane & 31)];
     }
@@ -458,7 +491,7 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
     constexpr int CSTEP = kMlpWaves / RBN;               // waves sharing a row block
     constexpr int HMAX = RGB ? (NHB + CSTEP - 1) / CSTEP : 1;
     const int rb = wave % RBN, cb0 = wave / RBN;
-    const float* ar = arow + rb * 32 * kLDA;
+    const float* ar = arow1 + rb * 32 * kLDA;
     const float* hb = bias + 8 * kW;
 #pragma unroll 1
     for (int i = 0; i < HMAX; ++i) {
@@ -586,7 +619,8 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   constexpr int kRows = 32 * RBN;
   constexpr int kWordsUsed = RBN * kCB * 16 / 32;
   const int C = rgb_channels(deg);
-  const float* arow = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
+  const ARows arow = make_arows(lds, lane);
+  const WImage wimg = make_wimage(pkb, bwd_image_floats(deg), lane);
   const bool full = row0 + kRows <= M;
   lds_barrier();   // previous tile's stores out of LDS are done
   // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
@@ -616,14 +650,14 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
     const uint32_t* mp = mask + ((slot * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords;
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb) + (wave * kCB) * 64 + lane;
-    gemm_prefetch_b<kCB>(wp, 4 * NHB, 8 * 64, bfrag);
-    gemm_lds_packed<RBN, kCB>(arow, wp, 4 * NHB, 8 * 64, acc, bfrag);
+    const int wp = (wave * kCB) * 64;      // wave-uniform f32x4 index into the image (head^T first)
+    gemm_prefetch_b<kCB>(wimg, wp, 4 * NHB, 8 * 64, bfrag);
+    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, 4 * NHB, 8 * 64, acc, bfrag);
   }
   for (int l = kDepth - 1; l >= 0; --l) {
     // the next GEMM's first weight fragments travel while this wave is in its epilogue
-    const f32x4* wp = reinterpret_cast<const f32x4*>(pkb + bwd_layer_off(l > 0 ? l : 1, deg)) + (wave * kCB) * 64 + lane;
-    if (l > 0) gemm_prefetch_b<kCB>(wp, 32, 8 * 64, bfrag);
+    const int wp = (int)(bwd_layer_off(l > 0 ? l : 1, deg) / 4) + (wave * kCB) * 64;
+    if (l > 0) gemm_prefetch_b<kCB>(wimg, wp, 32, 8 * 64, bfrag);
     lds_barrier();  // every wave has consumed the columns this wave is about to rewrite
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));   // see fwd_tile: keeps the epilogue addresses out of the loops' live set
@@ -651,7 +685,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
     const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
-    gemm_lds_packed<RBN, kCB>(arow, wp, 32, 8 * 64, acc, bfrag);
+    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, 32, 8 * 64, acc, bfrag);
   }
 }
 

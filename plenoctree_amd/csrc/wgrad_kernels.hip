@@ -71,75 +71,51 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     f32x4 xr[XV];
     f32x4 zr4[HEAD ? 1 : ZV];
     float zr1[HEAD ? ZV : 1];
-    uint32_t okx, okz;           // per-thread validity bits of the rows held in xr / zr4
   };
-  // Whole chunks (every chunk but possibly the last one of the last range) are loaded without row predicates from a
-  // wave-uniform base + a per-thread 32-bit element offset that does not change from chunk to chunk: the address
-  // arithmetic of the inner loop is then scalar (the per-load 64-bit VALU address math and the zero-selects of the
-  // predicated form were 107 VALU instructions per 64 MFMAs -- on the f32 lanes the MFMAs run on).
-  const float* __restrict__ Xb = X + r_begin * KIN;
-  const float* __restrict__ Zb = DUAL ? dZ + r_begin * kW : (HEAD ? dZ : dZ + r_begin * NOUT + ncol0);
-  const float* __restrict__ Zb2 = DUAL ? dZ2 + r_begin * kW : nullptr;
+  // Chunk loads are buffer loads on the WORKGROUP'S OWN ROW RANGE: base = first row of the range (wave-uniform), chunk
+  // offset = a scalar register, per-thread offset = one 32-bit register that never changes, and rows past the end of the
+  // range read as zeros by the buffer bounds check -- no row predicates, no zero-selects and no 64-bit vector address
+  // arithmetic in the loop (the predicated global_load form had 107 VALU instructions per 64 MFMAs, on the f32 lanes the
+  // MFMAs run on).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t range_rows = r_end - r_begin;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + r_begin * KIN), 0, (int)(range_rows * KIN * 4), 0x00020000);
+  constexpr int ZLD = DUAL ? kW : NOUT;             // row stride of a dZ array
+  const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HEAD ? dZ : dZ + r_begin * ZLD + (DUAL ? 0 : ncol0)), 0,
+      HEAD ? 0 : (int)((range_rows * ZLD - (DUAL ? 0 : ncol0)) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(DUAL ? dZ2 + r_begin * kW : dZ), 0, DUAL ? (int)(range_rows * kW * 4) : 0, 0x00020000);
   uint32_t xoff[XV], zoff[HEAD ? 1 : ZV];
 #pragma unroll
   for (int i = 0; i < XV; ++i) {
     const int idx = tid + NT * i;
-    xoff[i] = (uint32_t)((idx / (KIN / 4)) * KIN + (idx % (KIN / 4)) * 4);
+    xoff[i] = (uint32_t)((idx / (KIN / 4)) * KIN + (idx % (KIN / 4)) * 4) * 4u;
   }
   if (!HEAD) {
 #pragma unroll
     for (int i = 0; i < ZV; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
-      zoff[i] = DUAL ? (uint32_t)(row * kW + ((c4 * 4) & (kW - 1))) : (uint32_t)(row * NOUT + c4 * 4);
+      zoff[i] = (DUAL ? (uint32_t)(row * kW + ((c4 * 4) & (kW - 1))) : (uint32_t)(row * NOUT + c4 * 4)) * 4u;
     }
   }
   auto load_chunk = [&](int ch, Stage& st) {
-    const int64_t r0 = r_begin + (int64_t)ch * KCH;
-    const bool whole = r0 + KCH <= r_end;                   // wave-uniform
-    if (whole) {
-      st.okx = ~0u; st.okz = ~0u;
-      const float* __restrict__ xc = Xb + (int64_t)ch * (KCH * KIN);
 #pragma unroll
-      for (int i = 0; i < XV; ++i) st.xr[i] = *reinterpret_cast<const f32x4*>(xc + xoff[i]);
-      if (!HEAD) {
-        const float* __restrict__ zc = Zb + (int64_t)ch * (KCH * (DUAL ? kW : NOUT));
-        const float* __restrict__ zc2 = DUAL ? Zb2 + (int64_t)ch * (KCH * kW) : nullptr;
-#pragma unroll
-        for (int i = 0; i < ZV; ++i) {
-          const bool second = DUAL && ((tid + NT * i) % (NTILE / 4)) * 4 >= kW;
-          st.zr4[i] = *reinterpret_cast<const f32x4*>((second ? zc2 : zc) + zoff[i]);
-        }
-      }
-    } else {
-    st.okx = 0u; st.okz = 0u;
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = tid + NT * i;
-      const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
-      const int64_t grow = r0 + row;
-      const bool ok = grow < r_end;                      // rows past the range contribute zeros:
-      st.okx |= (ok ? 1u : 0u) << i;                     // selected at store time, so that nothing
-      st.xr[i] = *reinterpret_cast<const f32x4*>(X + (ok ? grow : r_begin) * KIN + c4 * 4);  // waits here
-    }
+    for (int i = 0; i < XV; ++i)
+      st.xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[i], ch * (KCH * KIN * 4), 0));
     if (!HEAD) {
+      // DUAL: a thread's float4 column (tid + NT i) % 128 lies in the second array iff its wave is odd (NT = 256,
+      // 128 float4 per row): a wave-uniform choice of the descriptor
+      static_assert(!DUAL || (NT == 256 && NTILE == 2 * kW), "dual source: wave parity selects the array");
+      const bool second = DUAL && (wave & 1);
 #pragma unroll
-      for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + NT * i;
-        const int row = idx / (NTILE / 4), c4 = idx % (NTILE / 4);
-        const int64_t grow = r0 + row;
-        const bool ok = grow < r_end;
-        st.okz |= (ok ? 1u : 0u) << i;
-        if (DUAL) {
-          const float* __restrict__ src = c4 * 4 < kW ? dZ : dZ2;
-          st.zr4[i] = *reinterpret_cast<const f32x4*>(src + (ok ? grow : r_begin) * kW + ((c4 * 4) & (kW - 1)));
-        } else {
-          st.zr4[i] = *reinterpret_cast<const f32x4*>(dZ + (ok ? grow : r_begin) * NOUT + ncol0 + c4 * 4);
-        }
-      }
-    }
-    }
-    if (HEAD) {
+      for (int i = 0; i < ZV; ++i)
+        st.zr4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsZ2 : rsZ, zoff[i],
+                                                                                     ch * (KCH * ZLD * 4), 0));
+    } else {
+      const int64_t r0 = r_begin + (int64_t)ch * KCH;
 #pragma unroll
       for (int i = 0; i < ZV; ++i) {
         const int idx = tid + NT * i;
@@ -155,28 +131,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     }
   };
   auto store_chunk = [&](int buf, const Stage& st) {
-    if (st.okx == ~0u && st.okz == ~0u) {                     // whole chunk (wave-uniform): no selects
 #pragma unroll
-      for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(&xs[buf][(tid + NT * i) * 4]) = st.xr[i];
-      if (!HEAD) {
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(&xs[buf][(tid + NT * i) * 4]) = st.xr[i];
+    if (!HEAD) {
 #pragma unroll
-        for (int i = 0; i < ZV; ++i) *reinterpret_cast<f32x4*>(&zs[buf][(tid + NT * i) * 4]) = st.zr4[i];
-      }
+      for (int i = 0; i < ZV; ++i) *reinterpret_cast<f32x4*>(&zs[buf][(tid + NT * i) * 4]) = st.zr4[i];
     } else {
-#pragma unroll
-      for (int i = 0; i < XV; ++i) {
-        const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(&xs[buf][idx * 4]) = ((st.okx >> i) & 1u) ? st.xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if (!HEAD) {
-#pragma unroll
-        for (int i = 0; i < ZV; ++i) {
-          const int idx = tid + NT * i;
-          *reinterpret_cast<f32x4*>(&zs[buf][idx * 4]) = ((st.okz >> i) & 1u) ? st.zr4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-    if (HEAD) {
 #pragma unroll
       for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = st.zr1[i];
     }

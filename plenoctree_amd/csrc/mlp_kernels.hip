@@ -253,10 +253,42 @@ __device__ __forceinline__ void gemm_prefetch_b(const WImage& w, int wu, int kgr
   for (int i = 0; i < kBDist; ++i) load_b<CBN>(w, wu, i < last ? i : last, kg_stride, b[i]);
 }
 
-template <int RBN, int CBN>
+// Copy of this wave's 32 columns of the tile the GEMM is reading (the previous layer's output) to HBM, one 8-row slab per
+// k-group during the first 4*RBN k-groups of the loop: the store path (64 B/clk per CU, 2048 cycles for a 128 KB tile) then
+// works beside the MFMAs instead of between the epilogue and the next GEMM.  No vector ALU work: LDS reads with immediate
+// offsets off two base registers, buffer stores with scalar row offsets.
+struct TileCopy {
+  __amdgpu_buffer_rsrc_t out;   // the tile's valid rows of the destination array
+  uint32_t voff;                // (rsub * 256 + wave * 32 + c4 * 4) * 4
+  const float* src;             // LDS: this lane's piece of slab 0
+  uint32_t src_hi;              // float offset of slab 8 (its own register: beyond the ds_read immediate range)
+  bool on;
+};
+template <int RBN>
+__device__ __forceinline__ TileCopy make_tile_copy(const float* lds, float* dst, int64_t row0, int64_t M, int wave, int lane,
+                                                   bool on) {
+  const int c4 = lane & 7, rsub = lane >> 3;
+  const int64_t rows = M - row0 < 32 * RBN ? M - row0 : 32 * RBN;
+  TileCopy t;
+  t.out = __builtin_amdgcn_make_buffer_rsrc(dst + row0 * kW, 0, on ? (int)(rows * kW * 4) : 0, 0x00020000);
+  t.voff = (uint32_t)(rsub * kW + wave * 32 + c4 * 4) * 4u;
+  t.src = lds + rsub * kLDA + wave * 32 + c4 * 4;
+  t.src_hi = 8 * 8 * kLDA;
+  asm volatile("" : "+v"(t.src_hi));
+  t.on = on;
+  return t;
+}
+template <int RBN>
+__device__ __forceinline__ void tile_copy_slab(const TileCopy& t, int i) {      // i: compile-time after unrolling
+  const f32x4 v = i < 8 ? *reinterpret_cast<const f32x4*>(t.src + i * 8 * kLDA)
+                        : *reinterpret_cast<const f32x4*>(t.src + t.src_hi + (i - 8) * 8 * kLDA);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), t.out, t.voff, i * 8 * kW * 4, 0);
+}
+
+template <int RBN, int CBN, bool COPY = false>
 __device__ __forceinline__ void gemm_lds_packed(const ARows& arow, const WImage& w, int wu,
                                                 int kgroups, int kg_stride, f32x16 (&acc)[RBN][CBN],
-                                                f32x4 (&b)[4][CBN]) {
+                                                f32x4 (&b)[4][CBN], const TileCopy* tc = nullptr) {
   constexpr int D = kBDist;
   static_assert(D == 2 || D == 3, "kBDist");
   f32x4 a0[RBN], a1[RBN];
@@ -270,21 +302,57 @@ __device__ __forceinline__ void gemm_lds_packed(const ARows& arow, const WImage&
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b[0], acc);
     PXO_PIN();
+    if (COPY && tc->on && g < 4 * RBN) {
+      switch (g >> 2) {
+        case 0: tile_copy_slab<RBN>(*tc, 0); break;
+        case 1: tile_copy_slab<RBN>(*tc, 4 + 0); break;
+        case 2: if (RBN > 2) tile_copy_slab<RBN>(*tc, 8 + 0); break;
+        default: if (RBN > 2) tile_copy_slab<RBN>(*tc, 12 + 0); break;
+      }
+      PXO_PIN();
+    }
     load_a<RBN>(arow, g + 2, a0);
     load_b<CBN>(w, wu, cl(g + 1 + D), kg_stride, b[(1 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b[1], acc);
     PXO_PIN();
+    if (COPY && tc->on && g < 4 * RBN) {
+      switch (g >> 2) {
+        case 0: tile_copy_slab<RBN>(*tc, 1); break;
+        case 1: tile_copy_slab<RBN>(*tc, 4 + 1); break;
+        case 2: if (RBN > 2) tile_copy_slab<RBN>(*tc, 8 + 1); break;
+        default: if (RBN > 2) tile_copy_slab<RBN>(*tc, 12 + 1); break;
+      }
+      PXO_PIN();
+    }
     load_a<RBN>(arow, g + 3, a1);
     load_b<CBN>(w, wu, cl(g + 2 + D), kg_stride, b[(2 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a0, b[2], acc);
     PXO_PIN();
+    if (COPY && tc->on && g < 4 * RBN) {
+      switch (g >> 2) {
+        case 0: tile_copy_slab<RBN>(*tc, 2); break;
+        case 1: tile_copy_slab<RBN>(*tc, 4 + 2); break;
+        case 2: if (RBN > 2) tile_copy_slab<RBN>(*tc, 8 + 2); break;
+        default: if (RBN > 2) tile_copy_slab<RBN>(*tc, 12 + 2); break;
+      }
+      PXO_PIN();
+    }
     load_a<RBN>(arow, cl(g + 4), a0);
     load_b<CBN>(w, wu, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);
     PXO_PIN();
     mfma_group<RBN, CBN>(a1, b[3], acc);
     PXO_PIN();
+    if (COPY && tc->on && g < 4 * RBN) {
+      switch (g >> 2) {
+        case 0: tile_copy_slab<RBN>(*tc, 3); break;
+        case 1: tile_copy_slab<RBN>(*tc, 4 + 3); break;
+        case 2: if (RBN > 2) tile_copy_slab<RBN>(*tc, 8 + 3); break;
+        default: if (RBN > 2) tile_copy_slab<RBN>(*tc, 12 + 3); break;
+      }
+      PXO_PIN();
+    }
   }
 }
 
@@ -329,26 +397,24 @@ __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 
 // that has just written them (no cross-wave ordering needed: a wave's LDS operations execute in order): per
 // instruction 8 rows x 128 B (whole 128-byte lines).  A workgroup-wide copy of whole 1 KiB rows needs a barrier between
 // the epilogue and the copy; without it the copy is issued right behind the wave's LDS writes and the forward / backward
-// kernels run 1.0 % / 2.9 % faster (round 3 A/B).
+// kernels run 1.0 % / 2.9 % faster (round 3 A/B).  The destination is a buffer bounded to the tile's valid rows: rows
+// past M are dropped by the bounds check, the row offset of every store is a scalar -- no predicates, no vector address math.
 template <int RBN>
 __device__ __forceinline__ void store_wave_cols(const float* __restrict__ lds, float* __restrict__ dst, int64_t row0,
-                                                int64_t M, bool full, int wave, int lane) {
+                                                int64_t M, int wave, int lane) {
   const int c4 = lane & 7, rsub = lane >> 3;
+  const int64_t rows = M - row0 < 32 * RBN ? M - row0 : 32 * RBN;
+  const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(dst + row0 * kW, 0, (int)(rows * kW * 4), 0x00020000);
+  const uint32_t voff = (uint32_t)(rsub * kW + wave * 32 + c4 * 4) * 4u;
   const float* __restrict__ src = lds + rsub * kLDA + wave * 32 + c4 * 4;
-  float* __restrict__ out = dst + (row0 + rsub) * kW + wave * 32 + c4 * 4;
 #pragma unroll
   for (int i0 = 0; i0 < 4 * RBN; i0 += 4) {      // four LDS reads in flight per four stores
     f32x4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (i0 + i) * 8 * kLDA);
-    if (full) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + (int64_t)(i0 + i) * 8 * kW) = v[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (row0 + (i0 + i) * 8 + rsub < M) *reinterpret_cast<f32x4*>(out + (int64_t)(i0 + i) * 8 * kW) = v[i];
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), out, voff, (i0 + i) * 8 * kW * 4, 0);
   }
 }
 
@@ -478,7 +544,9 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 #pragma unroll
       for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];
       // this wave's 32 columns leave for HBM right behind its LDS writes (no barrier in between)
-      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, wave, lane_e);
+      // (the forward kernel keeps this burst: copying the columns during the next GEMM, as the backward kernel does,
+      // measured 2.3 % slower here -- 4.15 vs 4.06 ms -- while it makes the backward kernel 3.2 % faster)
+      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);
     }
     lds_barrier();
   }
@@ -621,7 +689,6 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   const int C = rgb_channels(deg);
   const ARows arow = make_arows(lds, lane);
   const WImage wimg = make_wimage(pkb, bwd_image_floats(deg), lane);
-  const bool full = row0 + kRows <= M;
   lds_barrier();   // previous tile's stores out of LDS are done
   // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
   for (int idx = tid; idx < kRows * NH; idx += kMlpThreads) {
@@ -678,14 +745,16 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
       colsum += __shfl_xor(colsum, 32);
       if (lane_e < 32) my_db[l * kW + col] += colsum;
     }
-    store_wave_cols<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, full, wave, lane_e);
+    // dz_l leaves for HBM during the GEMM that reads it (TileCopy, below); only dz_0 has no GEMM behind it
+    if (l == 0) store_wave_cols<RBN>(lds, dz, row0, M, wave, lane_e);
     lds_barrier();
     if (l == 0) break;
     zero_acc(acc);
     const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
-    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, 32, 8 * 64, acc, bfrag);
+    const TileCopy tc = make_tile_copy<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, wave, lane, true);
+    gemm_lds_packed<RBN, kCB, true>(arow, wimg, wp, 32, 8 * 64, acc, bfrag, &tc);
   }
 }
 

@@ -172,6 +172,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     if (SCHED == 0 && do_ld) load_chunk(ld_ch, ld);
     const float* xa = &xs[buf][(wr * RB) * (KCH * 32) + lane];      // row (lane >> 5) of the k-step, column lane & 31
     const float* zb = &zs[buf][(wc * CB) * (KCH * 32) + lane];
+    // (A chunk staged as [32-column block][row][32 columns], which turns every operand read into ds_read2st64_b32 immediates
+    // off ONE base register -- 10 instead of 18 VALU per 64 MFMAs -- measured 0.65 % slower per step, round 3: not kept.)
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
     // otherwise sinks every ds_read to just before its use and waits lgkmcnt(0) every 4 MFMAs)
     float a0[RB], b0[CB], a1[RB], b1[CB];

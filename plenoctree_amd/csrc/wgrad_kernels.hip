@@ -2,9 +2,9 @@
 // M = rays*samples rows (the reverse-mode wgrad of nerf_sh/train.py:116 for the Dense layers of
 // nerf_sh/nerf/model_utils.py:60-94).
 //
-// Split-K: workgroup p owns a contiguous row range, streams 16-row chunks of X and dZ through
-// double-buffered LDS (with mfma_f32_32x32x2f32 the A^T/B fragments of a "TN" GEMM
-// are 32 consecutive floats of one row -> conflict-free ds_read_b32), keeps the whole
+// Split-K: workgroup p owns a contiguous row range, streams 32-row chunks of X and dZ through
+// double-buffered LDS (row-major: with mfma_f32_32x32x2f32 the A^T/B fragments of a "TN" GEMM
+// are 32 consecutive floats of one LDS row -> conflict-free ds_read_b32), keeps the whole
 // KIN x NOUT product in accumulators and writes one slab; a second kernel adds the slabs in a
 // fixed order (deterministic, no float atomics).
 #include <cstdlib>
@@ -130,30 +130,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
       }
     }
   };
-  // LDS layout of a staged chunk: [32-column block][row of the chunk][32 columns] (a block is KCH * 32 floats).  An MFMA
-  // operand read is then lds[block * KCH*32 + kstep * 64 + lane]: one base register (the lane id) and offsets that are
-  // multiples of 64 dwords -- the ds_read2st64_b32 immediates -- for every k-step and row / column block, instead of one
-  // address register re-derived per k-step (row-major chunks: 14 v_add_u32 per 64 MFMAs); a global float4 (4 columns of
-  // one row) still lands as one ds_write_b128.
-  auto lds_pos = [](int row, int col) { return (col >> 5) * (KCH * 32) + row * 32 + (col & 31); };
   auto store_chunk = [&](int buf, const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = tid + NT * i;
-      *reinterpret_cast<f32x4*>(&xs[buf][lds_pos(idx / (KIN / 4), (idx % (KIN / 4)) * 4)]) = st.xr[i];
-    }
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(&xs[buf][(tid + NT * i) * 4]) = st.xr[i];
     if (!HEAD) {
 #pragma unroll
-      for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + NT * i;
-        *reinterpret_cast<f32x4*>(&zs[buf][lds_pos(idx / (NTILE / 4), (idx % (NTILE / 4)) * 4)]) = st.zr4[i];
-      }
+      for (int i = 0; i < ZV; ++i) *reinterpret_cast<f32x4*>(&zs[buf][(tid + NT * i) * 4]) = st.zr4[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < ZV; ++i) {
-        const int idx = tid + NT * i;
-        zs[buf][lds_pos(idx / NTILE, idx % NTILE)] = st.zr1[i];
-      }
+      for (int i = 0; i < ZV; ++i) zs[buf][tid + NT * i] = st.zr1[i];
     }
   };
 
@@ -170,8 +155,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   auto run_chunk = [&](int ch, int buf, Stage& ld, int ld_ch, bool do_ld, const Stage& stg, bool do_st) {
     (void)ch;
     if (SCHED == 0 && do_ld) load_chunk(ld_ch, ld);
-    const float* xa = &xs[buf][(wr * RB) * (KCH * 32) + lane];      // row (lane >> 5) of the k-step, column lane & 31
-    const float* zb = &zs[buf][(wc * CB) * (KCH * 32) + lane];
+    const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
+    const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // (A chunk staged as [32-column block][row][32 columns], which turns every operand read into ds_read2st64_b32 immediates
     // off ONE base register -- 10 instead of 18 VALU per 64 MFMAs -- measured 0.65 % slower per step, round 3: not kept.)
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
@@ -179,9 +164,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     float a0[RB], b0[CB], a1[RB], b1[CB];
     auto read_step = [&](int kk, float (&a)[RB], float (&b)[CB]) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) a[r] = xa[r * (KCH * 32) + kk * 32];      // kk even: k-step kk / 2
+      for (int r = 0; r < RB; ++r) a[r] = xa[kk * KIN + r * 32];
 #pragma unroll
-      for (int c = 0; c < CB; ++c) b[c] = zb[c * (KCH * 32) + kk * 32];
+      for (int c = 0; c < CB; ++c) b[c] = zb[kk * NTILE + c * 32];
     };
     auto mfma_step = [&](const float (&a)[RB], const float (&b)[CB]) {
 #pragma unroll

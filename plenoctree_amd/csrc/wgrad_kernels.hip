@@ -339,12 +339,13 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
     set_error("wgrad workspace too small: %zu < %zu", ws_bytes, wgrad_workspace_bytes(cfg, M));
     return PXO_ERR_WORKSPACE;
   }
-  // the skinny products (enc-based pair, heads): two workgroups per CU (256 / 128 ranges measured equal or slower at
-  // 4096, 1024 and 512 rays per step).  Issuing them on side streams beside the 256x256 launch was measured too (round 3,
+  // the skinny products (enc-based pair, heads): two workgroups per CU.  Issuing them on side streams beside the 256x256 launch was measured too (round 3,
   // 512 rays per step): 4.05 vs 3.96 ms per step -- the HBM-leaning workgroups take CU slots from the MFMA-bound ones
   // early and the step gets longer, so the three launches stay in stream order.
   int64_t rpw2; int P2;
-  split_rows(M, 2 * (int64_t)num_cus(), &rpw2, &P2);
+  // (round 3, ms per step at 512 / 1024 / 4096 rays: 512 ranges 3.732 / 6.686 / 24.19, 256 ranges 3.716 / 6.689 / 24.28,
+  // 384: 3.739 / 6.722 / 24.41, 128: slower -- small passes take the 256, whose slabs cost the reduction half as much)
+  split_rows(M, M < (int64_t)512 * num_cus() ? (int64_t)num_cus() : 2 * (int64_t)num_cus(), &rpw2, &P2);
   const float* h7 = acts + (int64_t)7 * MW;
   auto head = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);

@@ -154,8 +154,9 @@ __device__ __forceinline__ void grid_point(const GridSpec& g, int64_t n, float& 
   pz = ((((float)iz + 0.5f) / (float)r) - g.off[2]) / g.scale[2];
 }
 
-// writes posenc of the tile's 32*RBN points into lds[:, 0:64]
-template <int RBN>
+// writes posenc of the tile's 32*RBN points into lds[:, 0:64]; GRID = false (the training kernels: points always come from
+// memory) keeps the 12 GridSpec scalars out of the kernel's SGPR budget
+template <int RBN, bool GRID = true>
 __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float* __restrict__ pts,
                                             const GridSpec& grid, int64_t row0, int64_t M, int tid) {
   constexpr int kRows = 32 * RBN;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float
   const int64_t grow = row0 + row;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
   if (grow < M) {
-    if (grid.enabled) grid_point(grid, grow, p0, p1, p2);
+    if (GRID && grid.enabled) grid_point(grid, grow, p0, p1, p2);
     else { p0 = pts[grow * 3]; p1 = pts[grow * 3 + 1]; p2 = pts[grow * 3 + 2]; }
   }
 #pragma unroll 4
@@ -456,7 +457,7 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   const WImage wimg = make_wimage(pk, fwd_image_floats(deg), lane);
   const bool full = row0 + kRows <= M;
   lds_barrier();   // previous tile's head GEMM has consumed the LDS tile
-  posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);
   lds_barrier();
   if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
 #pragma unroll

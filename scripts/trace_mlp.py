@@ -26,7 +26,7 @@ __device__ unsigned long long g_trace[2][4096];
 __device__ int g_trace_n[2];
 #define STAMP(k)                                                                                          \
   do {                                                                                                    \
-    if (trace_on && s_tn < 4000) {                                                                        \
+    if (trace_on && s_tn < 1536) {                                                                        \
       s_trace[s_tn] = ((unsigned long long)(((unsigned)(l) << 4) | (unsigned)(k)) << 48) |               \
                       (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFull);                                 \
       ++s_tn;                                                                                             \
@@ -43,21 +43,21 @@ def patch(src):
     # forward tile: trace state is handed in through two extra parameters
     s = s.replace("float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,\n                                         int wave) {",
                   "float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,\n                                         int wave, unsigned long long* s_trace, int& s_tn, bool trace_on) {", 1)
-    s = s.replace("  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN>(lds, pts, grid, row0, M, tid);\n  lds_barrier();",
-                  "  { const int l = 15; STAMP(14); }\n  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN>(lds, pts, grid, row0, M, tid);\n  lds_barrier();\n  { const int l = 15; STAMP(15); }", 1)
-    s = s.replace("    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);",
-                  "    STAMP(0);\n    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);\n    if (l != 5) STAMP(1);", 1)
-    s = s.replace("      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n    }",
-                  "      gemm_lds_packed<RBN, kCB>(arow, wp + (int64_t)32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n      STAMP(1);\n    }", 1)
+    s = s.replace("  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();",
+                  "  { const int l = 15; STAMP(14); }\n  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();\n  { const int l = 15; STAMP(15); }", 1)
+    s = s.replace("    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);",
+                  "    STAMP(0);\n    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);\n    if (l != 5) STAMP(1);", 1)
+    s = s.replace("      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n    }",
+                  "      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n      STAMP(1);\n    }", 1)
     s = s.replace("    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite\n    // re-derive the lane ids",
                   "    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite\n    STAMP(2);\n    // re-derive the lane ids", 1)
-    s = s.replace("      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      // this wave's 32 columns leave",
-                  "      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      STAMP(3);\n      // this wave's 32 columns leave", 1)
-    s = s.replace("      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, wave, lane_e);\n    }\n    lds_barrier();\n  }",
-                  "      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, full, wave, lane_e);\n      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n  }", 1)
+    s = s.replace("      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      // (the forward kernel keeps this burst",
+                  "      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      STAMP(3);\n      // (the forward kernel keeps this burst", 1)
+    s = s.replace("      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n    }\n    lds_barrier();\n  }",
+                  "      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n  }", 1)
     # kernel: trace buffers + flush
     s = s.replace("  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)\n    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,\n                                  mask, tid, lane, wave);",
-                  "  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];\n  __shared__ unsigned long long s_trace_all[2][1024];\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n  const bool trace_on = blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4);\n  unsigned long long* s_trace = s_trace_all[wave >> 2];\n  int s_tn = 0;\n  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x) {\n    if (s_tn > 900) s_tn = 0;      // keep the last tiles\n    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,\n                                  mask, tid, lane, wave, s_trace, s_tn, trace_on);\n  }", 1)
+                  "  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];\n  __shared__ unsigned long long s_trace_all[2][1536];\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n  const bool trace_on = blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4);\n  unsigned long long* s_trace = s_trace_all[wave >> 2];\n  int s_tn = 0;\n  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x) {\n    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,\n                                  mask, tid, lane, wave, s_trace, s_tn, trace_on);\n  }", 1)
     s = s.replace("    fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + h * (kTM / 2), ts.n_full + h,\n                                      raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);\n}",
                   "    fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + h * (kTM / 2), ts.n_full + h,\n                                      raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave, s_trace, s_tn, false);\n  if (trace_on) {\n    const int w = wave >> 2;\n    for (int i = 0; i < s_tn; ++i) g_trace[w][i] = s_trace[i];\n    g_trace_n[w] = s_tn;\n  }\n}", 1)
     s = s.replace("}  // namespace pxo", '''}  // namespace pxo
@@ -75,14 +75,14 @@ extern "C" int pxo_debug_trace(unsigned long long* out, int which, int cap) {
 def patch_skew(s):
     """EXPERIMENT (round 3, not shipped): waves 0-3 / 4-7 run the trunk layers one barrier-delimited phase apart -- GEMM over
     columns 0-127, GEMM over columns 128-255, epilogue -- so that a group's epilogue runs beside the other group's MFMAs."""
-    s = s.replace("                                                f32x4 (&b)[4][CBN]) {\n  constexpr int D = kBDist;",
-                  "                                                f32x4 (&b)[4][CBN], bool mid_barrier = false) {\n  constexpr int D = kBDist;", 1)
-    s = s.replace("    load_a<RBN>(arow, cl(g + 4), a0);\n    load_b<CBN>(wp, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);",
-                  "    if (mid_barrier && g + 4 == kgroups / 2) { lds_barrier(); PXO_PIN(); }\n    load_a<RBN>(arow, cl(g + 4), a0);\n    load_b<CBN>(wp, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);", 1)
+    s = s.replace("                                                f32x4 (&b)[4][CBN], const TileCopy* tc = nullptr) {\n  constexpr int D = kBDist;",
+                  "                                                f32x4 (&b)[4][CBN], const TileCopy* tc = nullptr, bool mid_barrier = false) {\n  constexpr int D = kBDist;", 1)
+    s = s.replace("    load_a<RBN>(arow, cl(g + 4), a0);\n    load_b<CBN>(w, wu, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);",
+                  "    if (mid_barrier && g + 4 == kgroups / 2) { lds_barrier(); PXO_PIN(); }\n    load_a<RBN>(arow, cl(g + 4), a0);\n    load_b<CBN>(w, wu, cl(g + 3 + D), kg_stride, b[(3 + D) & 3]);", 1)
     s = s.replace("  for (int l = 0; l < kDepth; ++l) {\n    // the accumulators start from the bias",
                   "  const int grp = wave >> 2;\n  for (int l = 0; l < kDepth; ++l) {\n    const bool skewed = l != 0 && l != 5;\n    if (grp == 1 && (l == 1 || l == 6)) lds_barrier();\n    // the accumulators start from the bias", 1)
-    s = s.replace("    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);",
-                  "    gemm_lds_packed<RBN, kCB>(arow, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag, skewed);", 1)
+    s = s.replace("    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);",
+                  "    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag, nullptr, skewed);", 1)
     s = s.replace("      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n  }",
                   "      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n    if (grp == 0 && (l == 4 || l == 7)) { lds_barrier(); STAMP(6); }\n  }", 1)
     s = s.replace("    if (grp == 1 && (l == 1 || l == 6)) lds_barrier();", "    if (grp == 1 && (l == 1 || l == 6)) { lds_barrier(); STAMP(7); }", 1)

@@ -455,6 +455,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tr["args"], a.cpu_rays, a.cpu_steps, job.device)
         print(json.dumps(out), flush=True)
+        # RCCL keeps its version banner in the C stdio buffer until the process exits: whatever libraries still flush to
+        # fd 1 after this point goes to stderr, so that the JSON line above stays the only line on stdout
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if job.dist:
         job.dist.barrier()
         job.dist.destroy_process_group()

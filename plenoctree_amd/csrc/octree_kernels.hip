@@ -337,6 +337,29 @@ __device__ __forceinline__ void to_tree_ray(const float (&origin)[3], const floa
 
 __device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.0f), 1.0f - 1e-6f); }
 
+// dda_unit for a point INSIDE the unit cell (0 <= cen < 1), as every march step calls it: the entry distance is then
+// max(0, non-positive values) = 0, and per axis the exit is t2 = t1 + invdir where invdir >= 0 and t1 = -cen * invdir
+// otherwise - one fused multiply-add per axis with the per-ray addend add = invdir >= 0 ? invdir : 0 (the same rounding as
+// the general routine, whose t1 + invdir the compiler contracts into that FMA).  Returns tmax (= tmax - tmin).
+struct CellExit {
+  float inv[3], add[3];
+  __device__ __forceinline__ void init(const float (&invdir)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      inv[a] = invdir[a];
+      add[a] = invdir[a] >= 0.0f ? invdir[a] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ float operator()(const float (&cen)[3]) const {
+    const float e0 = __builtin_fmaf(-cen[0], inv[0], add[0]);
+    const float e1 = __builtin_fmaf(-cen[1], inv[1], add[1]);
+    const float e2 = __builtin_fmaf(-cen[2], inv[2], add[2]);
+    return fminf(fminf(1e9f, e0), fminf(e1, e2));
+  }
+};
+// 2^-(depth+1) exactly: dividing the cell-local distance by the cell count per axis (a power of two) is this multiplication
+__device__ __forceinline__ float inv_cells(int depth) { return __int_as_float((126 - depth) << 23); }
+
 // ------------------------------------------------------------------------------------------
 // grid weight render: one thread per (camera, pixel)
 // ------------------------------------------------------------------------------------------
@@ -368,7 +391,9 @@ __global__ void unbrick_max_kernel(const float* __restrict__ bricked, int reso, 
   lin[i] = fmaxf(lin[i], bricked[brick_index(x, y, z, reso >> 2)]);
 }
 
-template <bool BRICK>
+// POW2: reso is a power of two (every grid the extraction makes): the division by it is an exact multiplication and
+// the brick index is assembled from bit fields in 32 bits (reso <= 1024).
+template <bool BRICK, bool POW2>
 __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restrict__ sigma, int reso,
                                                            const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
                                                            int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
@@ -388,6 +413,10 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
   to_tree_ray(origin, dir, offset.v, invradius.v, r);
   if (r.tmax < 0.0f || r.tmin > r.tmax) return;
   const float cube = (float)reso;
+  const float inv_cube = 1.0f / cube;            // exact when POW2
+  const int lb = 31 - __clz(reso >> 2);          // POW2: log2 of bricks per axis
+  CellExit cell_exit;
+  cell_exit.init(r.invdir);
   float t = r.tmin, light = 1.0f;
   while (t < r.tmax) {
     float local[3];
@@ -395,14 +424,18 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float p = clamp_coord(r.o[a] + t * r.d[a]) * cube;
-      const float fl = floorf(p);
-      c[a] = (int)fl;
-      local[a] = p - fl;
+      c[a] = (int)p;                             // p >= 0: truncation == floor
+      local[a] = __builtin_amdgcn_fractf(p);     // p - floor(p)
     }
-    float s0, s1;
-    dda_unit(local, r.invdir, s0, s1);
-    const float delta_t = (s1 - s0) / cube + opt.step_size;
-    const int64_t idx = BRICK ? brick_index(c[0], c[1], c[2], reso >> 2) : ((int64_t)c[0] * reso + c[1]) * reso + c[2];
+    const float s1 = cell_exit(local);
+    const float delta_t = (POW2 ? s1 * inv_cube : s1 / cube) + opt.step_size;
+    int64_t idx;
+    if (BRICK && POW2) {
+      const uint32_t x = (uint32_t)c[0], y = (uint32_t)c[1], z = (uint32_t)c[2];
+      idx = (uint32_t)(((x >> 2) << (2 * lb + 6)) | ((y >> 2) << (lb + 6)) | ((z >> 2) << 6) | ((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
+    } else {
+      idx = BRICK ? brick_index(c[0], c[1], c[2], reso >> 2) : ((int64_t)c[0] * reso + c[1]) * reso + c[2];
+    }
     const float sg = sigma[idx];
     if (sg > opt.sigma_thresh) {
       const float att = expf(-(delta_t * r.delta_scale) * sg);
@@ -559,6 +592,8 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
   const float bg = A.opt.background_brightness;
   TreeRay r;
   to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
+  CellExit cell_exit;
+  cell_exit.init(r.invdir);
   const bool miss = r.tmax < 0.0f || r.tmin > r.tmax;
   if (MODE == 0 && miss) {
     for (int c = l; c < 3; c += kRow) out_rgb[ray * 3 + c] = bg;
@@ -629,13 +664,8 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
       const float cube = (float)(2u << depth);
       float local[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float p = pos[a] * cube;
-        local[a] = p - floorf(p);
-      }
-      float s0, s1;
-      dda_unit(local, r.invdir, s0, s1);
-      const float delta_t = (s1 - s0) / cube + A.opt.step_size;
+      for (int a = 0; a < 3; ++a) local[a] = __builtin_amdgcn_fractf(pos[a] * cube);
+      const float delta_t = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
       const float* __restrict__ val = data + leaf * D;
       const float sg = val[D - 1];
       if (sg > A.opt.sigma_thresh) {
@@ -749,15 +779,19 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
 // 4g + q from that ray's lanes (shfl) and adds basis_k(ray) * d_channel at the data indices j, j + 16, .. - the same 64-byte rows per
 // instruction as the 16-lane kernel, with the march running at four times its rays per wave.  Rays that have finished stay in
 // the loop (idle) until the whole wave is done, since every lane takes part in every deal.
-template <int KF>
+template <int KF, int WC>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(RenderArgs A, const float* __restrict__ fwd_rgb,
                                                                              const float* __restrict__ grad_out,
                                                                              float* __restrict__ grad_data) {
   using G = RowGeom<4>;
   constexpr int kRow = 4, kRaysPerBlock = G::kRaysPerBlock;
+  constexpr int kDmax = 3 * (KF > 0 ? KF : 25) + 1, kRM = (kDmax + 63) / 64, kWCn = WC > 0 ? WC : 1;
   __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
   __shared__ float s_basis[kRaysPerBlock][25];
-  const int row = threadIdx.x / kRow, l = threadIdx.x % kRow, lane = threadIdx.x & 63;
+  __shared__ float s_rows[kRenderThreads / 64][kWCn][WC > 0 ? kDmax : 1];
+  static_assert(WC <= 64, "one tag per lane");
+  const int row = threadIdx.x / kRow, l = threadIdx.x % kRow, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tagv = -1;                                 // lane i: the leaf whose row sits in slot i of this wave's cache (-1: empty)
   int64_t ray = 0;
   float origin[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f}, vdir[3] = {0.f, 0.f, 1.f};
   bool active = true;
@@ -791,6 +825,8 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
   const float bg = A.opt.background_brightness;
   TreeRay r;
   to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
+  CellExit cell_exit;
+  cell_exit.init(r.invdir);
   const bool alive = active && !(r.tmax < 0.0f || r.tmin > r.tmax);
 
   if (l == 0) {
@@ -821,6 +857,14 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq)
       sb[gq][m] = sch[m] >= 0 ? s_basis[wave_row0 + 4 * gq + (lane >> 4)][idx - sch[m] * Kc] : 0.0f;
+  }
+  // write-combining side: the wave's lane owns the data indices lane, lane + 64 of whatever row is being updated
+  int wch[kRM], wof[kRM];
+#pragma unroll
+  for (int m = 0; m < kRM; ++m) {
+    const int idx = lane + 64 * m;
+    wch[m] = idx < 3 * Kc ? idx / Kc : 3;
+    wof[m] = idx < 3 * Kc ? idx - wch[m] * Kc : 0;
   }
   const float* __restrict__ data = A.tree.data;
   const int32_t* __restrict__ child = A.tree.child;
@@ -855,13 +899,8 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
         const float cube = (float)(2u << depth);
         float local[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float p = pos[a] * cube;
-          local[a] = p - floorf(p);
-        }
-        float s0, s1;
-        dda_unit(local, r.invdir, s0, s1);
-        const float delta_t = (s1 - s0) / cube + A.opt.step_size;
+        for (int a = 0; a < 3; ++a) local[a] = __builtin_amdgcn_fractf(pos[a] * cube);
+        const float delta_t = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
         const float* __restrict__ val = data + leaf * D;
         const float sg = val[D - 1];
         if (sg > A.opt.sigma_thresh) {
@@ -915,7 +954,39 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
         running = tn > t && tn < r.tmax;           // !(tn > t): step below the resolution of t, stop rather than spin
         t = tn;
       }
-      if (pass == 1) {
+      if (pass == 1 && WC > 0) {
+        // one sample at a time, the whole wave on its row: hit -> add in LDS; miss -> the evicted row leaves as ONE
+        // contiguous row of atomics, the new row starts from this sample
+        uint64_t hm = __builtin_amdgcn_ballot_w64(has && l == 0);
+        while (hm) {
+          const int src = __builtin_ctzll(hm);
+          hm &= hm - 1;
+          const int lf = __builtin_amdgcn_readlane(leaf_i, src);
+          const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0), src));
+          const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1), src));
+          const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2), src));
+          const float qs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(es), src));
+          const int slot = (int)(((uint32_t)lf * 2654435761u) >> 16) & (kWCn - 1);
+          const int tag = __builtin_amdgcn_readlane(tagv, slot);
+          float* rowp = s_rows[wave][slot];
+          const float* bas = s_basis[wave_row0 + (src >> 2)];
+#pragma unroll
+          for (int m = 0; m < kRM; ++m) {
+            const int idx = lane + 64 * m;
+            if (idx < D) {
+              const float v = wch[m] < 3 ? bas[wof[m]] * (wch[m] == 0 ? q0 : (wch[m] == 1 ? q1 : q2)) : qs;
+              if (tag == lf) {
+                rowp[idx] += v;
+              } else {
+                if (tag >= 0) unsafeAtomicAdd(grad_data + (int64_t)tag * D + idx, rowp[idx]);
+                rowp[idx] = v;
+              }
+            }
+          }
+          tagv = lane == slot ? lf : tagv;
+        }
+      }
+      if (pass == 1 && WC == 0) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int src = 4 * (4 * gq + (lane >> 4));            // first lane of the served ray's row
@@ -935,6 +1006,17 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
       }
     }
     if (pass == 0) accum = (g[0] * (out[0] + light * bg) + g[1] * (out[1] + light * bg)) + g[2] * (out[2] + light * bg);
+  }
+  if (WC > 0) {                                  // rows still held by the wave
+    for (int sl = 0; sl < WC; ++sl) {
+      const int tag = __builtin_amdgcn_readlane(tagv, sl);
+      if (tag < 0) continue;
+#pragma unroll
+      for (int m = 0; m < kRM; ++m) {
+        const int idx = lane + 64 * m;
+        if (idx < D) unsafeAtomicAdd(grad_data + (int64_t)tag * D + idx, s_rows[wave][sl][idx]);
+      }
+    }
   }
 }
 
@@ -1134,10 +1216,11 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   Vec3 o{{offset[0], offset[1], offset[2]}}, ir{{invradius[0], invradius[1], invradius[2]}};
   const int64_t tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
   PXO_REQUIRE(tiles * n_cams < ((int64_t)1 << 31), "pxo_grid_weight_render: too many tiles for one launch");
+  const unsigned gw_grid = (unsigned)(tiles * n_cams);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)reso * reso * reso;
   if (reso % 4 != 0) {   // grids that do not tile into bricks (never the case for 2^(depth+1), depth >= 1)
-    hipLaunchKernelGGL(grid_weight_kernel<false>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, sigma_grid, reso, c2w_all,
+    hipLaunchKernelGGL((grid_weight_kernel<false, false>), dim3(gw_grid), dim3(256), 0, s, sigma_grid, reso, c2w_all,
                        n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(grid_weight));
     return check_launch("grid_weight_render");
   }
@@ -1153,8 +1236,13 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
     return PXO_ERR_HIP;
   }
   hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, sigma_grid, reso, sigma_b);
-  hipLaunchKernelGGL(grid_weight_kernel<true>, dim3((unsigned)(tiles * n_cams)), dim3(256), 0, s, (const float*)sigma_b, reso,
-                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
+  static const int gw_lds = [] { const char* e = getenv("PXO_GW_LDS"); return e ? atoi(e) : 0; }();
+  if ((reso & (reso - 1)) == 0 && reso <= 1024)
+    hipLaunchKernelGGL((grid_weight_kernel<true, true>), dim3(gw_grid), dim3(256), gw_lds, s, (const float*)sigma_b, reso,
+                       c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
+  else
+    hipLaunchKernelGGL((grid_weight_kernel<true, false>), dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso,
+                       c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
   hipLaunchKernelGGL(unbrick_max_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, (const float*)weight_b, reso,
                      grid_weight);
   return check_launch("grid_weight_render");
@@ -1182,6 +1270,17 @@ static int render_row(bool backward, int data_dim) {
   if (forced) return forced;
   (void)data_dim;
   return 4;
+}
+
+// Rows of the backward kernel's per-wave write-combining cache.  Measured (800x800, SH16, reusing the forward image):
+// 9.7 ms direct scatter, 5.0 / 4.8 / 4.4 / 4.3 ms with 4 / 8 / 16 / 32 rows; two-march form 10.3 -> 6.3 / 6.1 / 5.6 / 6.3 (32 rows
+// cost occupancy: 35 KB of LDS per workgroup).  PXO_OCT_WC = 0 | 4 | 8 | 16 | 32 | 64 forces one value for A/B runs.
+static int bwd_wc_slots() {
+  static const int v = [] {
+    const char* e = getenv("PXO_OCT_WC");
+    return e ? atoi(e) : 16;
+  }();
+  return v;
 }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
@@ -1270,12 +1369,22 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
               (double)opts->stop_thresh);
   switch (row) {
     case 4:
-#define PXO_BWD4(KF_) hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, grad_out, grad_data)
+#define PXO_BWD4W(KF_, WC_) hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_, WC_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, grad_out, grad_data)
+#define PXO_BWD4(KF_)                                     \
+  switch (bwd_wc_slots()) {                               \
+    case 4: PXO_BWD4W(KF_, 4); break;                     \
+    case 8: PXO_BWD4W(KF_, 8); break;                     \
+    case 16: PXO_BWD4W(KF_, 16); break;                   \
+    case 32: PXO_BWD4W(KF_, 32); break;                   \
+    case 64: PXO_BWD4W(KF_, 64); break;                   \
+    default: PXO_BWD4W(KF_, 0); break;                    \
+  }
       switch (tree->basis_dim) {
         case 16: PXO_BWD4(16); break;
         case 25: PXO_BWD4(25); break;
         default: PXO_BWD4(-1); break;
       }
+#undef PXO_BWD4W
 #undef PXO_BWD4
       break;
     case 8: hipLaunchKernelGGL((octree_render_kernel<1, 8>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;

@@ -37,6 +37,7 @@ def main():
     p.add_argument("--step", type=float, default=1e-4)
     p.add_argument("--cams", type=int, default=8)
     p.add_argument("--basis", type=int, default=16, help="SH basis_dim of the tree data (16 or 25)")
+    p.add_argument("--gw-only", action="store_true", help="stop after grid_weight_render (A/B of that kernel)")
     a = p.parse_args()
     from plenoctree_amd import build, octree_ops as oops
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
@@ -66,6 +67,10 @@ def main():
     out["grid_weight_Mrays_per_s"] = a.cams * W * H / ms / 1e3
     mask = oops.threshold_mask(wt, 1e-3)
     out["mask_voxels"] = int(mask.sum())
+    out["weight_sum"] = float(wt.double().sum())
+    if a.gw_only:
+        print(json.dumps(out), flush=True)
+        return
     t0 = time.perf_counter()
     child, pd, levels = oops.tree_from_mask(mask, depth)
     torch.cuda.synchronize()
@@ -83,18 +88,24 @@ def main():
     leaf.copy_(torch.randn(leaf.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 0.5)
     leaf[:, -1] = sig[(idx[:, 0] * reso + idx[:, 1]) * reso + idx[:, 2]]
     r = VolumeRenderer(tree, step_size=a.step)
+    def render_all(fast):
+        with torch.no_grad():
+            return [r.render_persp(c, width=W, height=H, fx=focal, fast=fast) for c in cams]
+
     for fast in (False, True):
-        ms = timed(lambda: [r.render_persp(c, width=W, height=H, fx=focal, fast=fast) for c in cams], reps=2) / a.cams
+        ms = timed(lambda: render_all(fast), reps=2) / a.cams
         key = "fast" if fast else "exact"
         out[f"render_{key}_ms_per_image"] = ms
         out[f"render_{key}_Mrays_per_s"] = W * H / ms / 1e3
         out[f"render_{key}_fps"] = 1e3 / ms
-    im = r.render_persp(cams[0], width=W, height=H, fx=focal)
+    with torch.no_grad():
+        im = r.render_persp(cams[0], width=W, height=H, fx=focal)
     out["image_mean"] = float(im.mean())
+    out["image_sum"] = float(im.double().sum())
     gt = torch.rand_like(im)
     grad = torch.zeros_like(tree.data)
 
-    ims = [r.render_persp(c, width=W, height=H, fx=focal) for c in cams]
+    ims = render_all(False)
 
     def bwd(reuse):
         for c, imc in zip(cams, ims):
@@ -105,6 +116,7 @@ def main():
         key = "render_bwd_reusing_fwd" if reuse else "render_bwd"
         out[f"{key}_ms_per_image"] = ms
         out[f"{key}_Mrays_per_s"] = W * H / ms / 1e3
+    out["grad_abs_sum"] = float(grad.double().abs().sum())
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
     out["tree_data_MB"] = tree.data.numel() * 4 / 1e6
     print(json.dumps(out), flush=True)

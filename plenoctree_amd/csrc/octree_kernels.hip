@@ -451,6 +451,164 @@ __global__ __launch_bounds__(256) void grid_weight_kernel(const float* __restric
   }
 }
 
+// Slab-staged form for power-of-two bricked grids.  A workgroup is a 16x16-pixel tile whose rays sweep the grid together,
+// one brick layer ("slab", 4 voxels thick along the dominant axis of the tile's centre ray) at a time: the kWin x kWin bricks
+// of that layer around the centre ray are copied to LDS with 16-byte coalesced loads, every ray takes its samples of the slab
+// from LDS (sigma) and folds its weights into an LDS copy of the same bricks (ds_max), and the touched weights leave as whole
+// bricks (one global atomicMax per voxel and tile instead of a read and possibly an atomic per sample).  Per ray the arithmetic
+// and the order of its samples are those of grid_weight_kernel, and max is order-free, so the result is bit-identical.
+// Samples outside the window (rare: the window is 24 voxels wide, a tile's footprint at most ~14 + the slab's drift) and rays
+// that do not advance along the sweep direction take the global path of the plain kernel.
+template <int kWin>
+__global__ __launch_bounds__(256) void grid_weight_slab_kernel(const float* __restrict__ sigma, int reso,
+                                                                const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
+                                                                int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
+                                                                int* __restrict__ weight_bits) {
+  __shared__ float s_sigma[kWin * kWin * 64];
+  __shared__ int s_w[kWin * kWin * 64];
+  __shared__ int s_first;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const int64_t b = blockIdx.x;
+  const int cam = (int)(b / ((int64_t)tiles_x * tiles_y));
+  const int tile = (int)(b % ((int64_t)tiles_x * tiles_y));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx0 = (tile % tiles_x) * 16, ty0 = (tile / tiles_x) * 16;
+  const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
+  const float* c2w = c2w_all + (int64_t)cam * 12;
+  const int nb = reso >> 2, lb = 31 - __clz(nb);
+  const float cube = (float)reso, inv_cube = 1.0f / cube;
+
+  // the tile's centre ray fixes the sweep: axis A, direction sgn, and where the window sits in every slab (workgroup-uniform)
+  TreeRay rc;
+  {
+    float oc[3], dc[3];
+    camera_ray(c2w, fx, fy, W, H, min(tx0 + 8, W - 1), min(ty0 + 8, H - 1), oc, dc);
+    to_tree_ray(oc, dc, offset.v, invradius.v, rc);
+  }
+  const float ad0 = fabsf(rc.d[0]), ad1 = fabsf(rc.d[1]), ad2 = fabsf(rc.d[2]);
+  const int A = ad0 >= ad1 && ad0 >= ad2 ? 0 : (ad1 >= ad2 ? 1 : 2), B = A == 0 ? 1 : 0, C = A == 2 ? 1 : 2;
+  const int sgn = rc.d[A] >= 0.0f ? 1 : -1;
+  // bit position of an axis' brick coordinate / in-brick coordinate in the bricked index (brick_index: x slowest)
+  const int shA = (2 - A) * lb + 6, shB = (2 - B) * lb + 6, shC = (2 - C) * lb + 6;
+  const int lsA = (2 - A) * 2, lsB = (2 - B) * 2, lsC = (2 - C) * 2;
+
+  for (int e = tid; e < kWin * kWin * 64; e += 256) s_w[e] = 0;
+  if (tid == 0) s_first = 0x7fffffff;
+
+  // this thread's ray, axes permuted to (A, B, C)
+  float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f}, delta_scale = 0.0f, tmax = 0.0f, t = 0.0f, light = 1.0f;
+  CellExit cell_exit;
+  bool alive = cam < n_cams && px < W && py < H;
+  {
+    float origin[3], dir[3];
+    TreeRay r;
+    camera_ray(c2w, fx, fy, W, H, min(px, W - 1), min(py, H - 1), origin, dir);
+    to_tree_ray(origin, dir, offset.v, invradius.v, r);
+    alive = alive && !(r.tmax < 0.0f || r.tmin > r.tmax) && r.tmin < r.tmax;
+    const int perm[3] = {A, B, C};
+    float pinv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      po[i] = perm[i] == 0 ? r.o[0] : (perm[i] == 1 ? r.o[1] : r.o[2]);
+      pd[i] = perm[i] == 0 ? r.d[0] : (perm[i] == 1 ? r.d[1] : r.d[2]);
+      pinv[i] = perm[i] == 0 ? r.invdir[0] : (perm[i] == 1 ? r.invdir[1] : r.invdir[2]);
+    }
+    cell_exit.init(pinv);
+    delta_scale = r.delta_scale;
+    tmax = r.tmax;
+    t = r.tmin;
+  }
+  // the pending sample: cell (permuted axes) and step length at the current t
+  int c0 = 0, c1 = 0, c2 = 0;
+  float delta_t = 0.0f;
+  auto next_sample = [&]() {
+    float local[3];
+    const float p0 = clamp_coord(po[0] + t * pd[0]) * cube, p1 = clamp_coord(po[1] + t * pd[1]) * cube,
+                p2 = clamp_coord(po[2] + t * pd[2]) * cube;
+    c0 = (int)p0; c1 = (int)p1; c2 = (int)p2;
+    local[0] = __builtin_amdgcn_fractf(p0); local[1] = __builtin_amdgcn_fractf(p1); local[2] = __builtin_amdgcn_fractf(p2);
+    delta_t = cell_exit(local) * inv_cube + opt.step_size;
+  };
+  if (alive) next_sample();
+  __syncthreads();
+  if (alive) atomicMin(&s_first, (c0 >> 2) * sgn);
+  __syncthreads();
+  const int first = s_first;
+  if (first == 0x7fffffff) return;               // no ray of the tile meets the grid (workgroup-uniform)
+
+  const float cinvA = rc.invdir[A], coA = rc.o[A];
+  const float coB = rc.o[B], cdB = rc.d[B], coC = rc.o[C], cdC = rc.d[C];
+  for (int key = first;; ++key) {
+    const int k = key * sgn;
+    if (k < 0 || k >= nb) break;
+    // window: kWin x kWin bricks of layer k around the centre ray at the layer's mid-plane
+    const float tc = ((float)(4 * k + 2) * inv_cube - coA) * cinvA;
+    const int wb0 = (int)floorf((coB + tc * cdB) * cube * 0.25f - 0.5f * (kWin - 1));
+    const int wc0 = (int)floorf((coC + tc * cdC) * cube * 0.25f - 0.5f * (kWin - 1));
+    for (int e = tid; e < kWin * kWin * 16; e += 256) {
+      const int br = e >> 4, q = e & 15;
+      const int bi = wb0 + br / kWin, bj = wc0 + br % kWin;
+      if ((unsigned)bi < (unsigned)nb && (unsigned)bj < (unsigned)nb) {
+        const uint32_t base = ((uint32_t)k << shA) | ((uint32_t)bi << shB) | ((uint32_t)bj << shC);
+        *reinterpret_cast<float4*>(s_sigma + br * 64 + q * 4) = *reinterpret_cast<const float4*>(sigma + base + q * 4);
+      }
+    }
+    __syncthreads();
+    while (alive && ((c0 >> 2) - k) * sgn <= 0) {
+      const int i = (c1 >> 2) - wb0, j = (c2 >> 2) - wc0;
+      const bool inwin = (c0 >> 2) == k && (unsigned)i < (unsigned)kWin && (unsigned)j < (unsigned)kWin;
+      const uint32_t low = ((uint32_t)(c0 & 3) << lsA) | ((uint32_t)(c1 & 3) << lsB) | ((uint32_t)(c2 & 3) << lsC);
+      const int lidx = (i * kWin + j) * 64 + (int)low;
+      const uint32_t gidx = ((uint32_t)(c0 >> 2) << shA) | ((uint32_t)(c1 >> 2) << shB) | ((uint32_t)(c2 >> 2) << shC) | low;
+      const float sg = inwin ? s_sigma[lidx] : sigma[gidx];
+      if (sg > opt.sigma_thresh) {
+        const float att = expf(-(delta_t * delta_scale) * sg);
+        const float w = light * (1.0f - att);
+        light = light * att;
+        const int wb = __float_as_int(w);                                  // w >= 0: integer order == float order
+        if (inwin) atomicMax(&s_w[lidx], wb);
+        else if (wb > weight_bits[gidx]) atomicMax(weight_bits + gidx, wb);
+        if (light <= opt.stop_thresh) alive = false;
+      }
+      const float tn = t + delta_t;
+      if (!(tn > t)) alive = false;              // step below the resolution of t: stop rather than spin
+      t = tn;
+      if (!(t < tmax)) alive = false;
+      if (alive) next_sample();
+    }
+    const int more = __syncthreads_or(alive ? 1 : 0);
+    for (int e = tid; e < kWin * kWin * 64; e += 256) {
+      const int wv = s_w[e];
+      if (wv > 0) {
+        const int br = e >> 6;
+        const uint32_t g = ((uint32_t)k << shA) | ((uint32_t)(wb0 + br / kWin) << shB) | ((uint32_t)(wc0 + br % kWin) << shC) | (uint32_t)(e & 63);
+        if (wv > weight_bits[g]) atomicMax(weight_bits + g, wv);
+        s_w[e] = 0;
+      }
+    }
+    if (!more) return;
+  }
+  // rays still alive after the last layer of the sweep (none in practice): the plain per-sample path
+  while (alive) {
+    const uint32_t low = ((uint32_t)(c0 & 3) << lsA) | ((uint32_t)(c1 & 3) << lsB) | ((uint32_t)(c2 & 3) << lsC);
+    const uint32_t gidx = ((uint32_t)(c0 >> 2) << shA) | ((uint32_t)(c1 >> 2) << shB) | ((uint32_t)(c2 >> 2) << shC) | low;
+    const float sg = sigma[gidx];
+    if (sg > opt.sigma_thresh) {
+      const float att = expf(-(delta_t * delta_scale) * sg);
+      const float w = light * (1.0f - att);
+      light = light * att;
+      const int wb = __float_as_int(w);
+      if (wb > weight_bits[gidx]) atomicMax(weight_bits + gidx, wb);
+      if (light <= opt.stop_thresh) break;
+    }
+    const float tn = t + delta_t;
+    if (!(tn > t)) break;
+    t = tn;
+    if (!(t < tmax)) break;
+    next_sample();
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // octree renderer
 // ------------------------------------------------------------------------------------------
@@ -1236,9 +1394,14 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
     return PXO_ERR_HIP;
   }
   hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)blocks_for(n, 256)), dim3(256), 0, s, sigma_grid, reso, sigma_b);
-  static const int gw_lds = [] { const char* e = getenv("PXO_GW_LDS"); return e ? atoi(e) : 0; }();
-  if ((reso & (reso - 1)) == 0 && reso <= 1024)
-    hipLaunchKernelGGL((grid_weight_kernel<true, true>), dim3(gw_grid), dim3(256), gw_lds, s, (const float*)sigma_b, reso,
+  // window width measured at 4 / 5 / 6 bricks: 1.245 / 1.257 / 1.262 ms per camera (the staging is not what bounds the kernel);
+  // 6 keeps nearly every sample of a 16x16 tile inside.  PXO_GW_SLAB=0 selects the per-sample kernel (A/B, the equality test).
+  const char* gw_env = getenv("PXO_GW_SLAB");
+  if ((reso & (reso - 1)) == 0 && reso <= 1024 && !(gw_env && atoi(gw_env) == 0))
+    hipLaunchKernelGGL(grid_weight_slab_kernel<6>, dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso,
+                       c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
+  else if ((reso & (reso - 1)) == 0 && reso <= 1024)
+    hipLaunchKernelGGL((grid_weight_kernel<true, true>), dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso,
                        c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
   else
     hipLaunchKernelGGL((grid_weight_kernel<true, false>), dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso,

@@ -337,10 +337,11 @@ __device__ __forceinline__ void to_tree_ray(const float (&origin)[3], const floa
 
 __device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.0f), 1.0f - 1e-6f); }
 
-// dda_unit for a point INSIDE the unit cell (0 <= cen < 1), as every march step calls it: the entry distance is then
-// max(0, non-positive values) = 0, and per axis the exit is t2 = t1 + invdir where invdir >= 0 and t1 = -cen * invdir
-// otherwise - one fused multiply-add per axis with the per-ray addend add = invdir >= 0 ? invdir : 0 (the same rounding as
-// the general routine, whose t1 + invdir the compiler contracts into that FMA).  Returns tmax (= tmax - tmin).
+// dda_unit for a point INSIDE the unit cell (0 <= cen < 1), as every march step calls it.  The entry distance is then
+// max(0, non-positive values) = 0, and per axis the exit is max(t1, t2) with t1 = -cen * invdir, t2 = t1 + invdir: t2 when
+// invdir >= 0, t1 otherwise - i.e. t1 + add with the per-ray addend add = invdir >= 0 ? invdir : 0 (t1 + 0 is t1).  Same
+// operations, same roundings as dda_unit (this file is compiled without contraction), 9 instructions instead of 19.
+// Returns tmax (= tmax - tmin).
 struct CellExit {
   float inv[3], add[3];
   __device__ __forceinline__ void init(const float (&invdir)[3]) {
@@ -351,9 +352,9 @@ struct CellExit {
     }
   }
   __device__ __forceinline__ float operator()(const float (&cen)[3]) const {
-    const float e0 = __builtin_fmaf(-cen[0], inv[0], add[0]);
-    const float e1 = __builtin_fmaf(-cen[1], inv[1], add[1]);
-    const float e2 = __builtin_fmaf(-cen[2], inv[2], add[2]);
+    const float e0 = -cen[0] * inv[0] + add[0];
+    const float e1 = -cen[1] * inv[1] + add[1];
+    const float e2 = -cen[2] * inv[2] + add[2];
     return fminf(fminf(1e9f, e0), fminf(e1, e2));
   }
 };

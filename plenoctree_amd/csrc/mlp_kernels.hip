@@ -450,6 +450,11 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
                                          int wave) {
   constexpr int kRows = 32 * RBN;
   constexpr int kWordsUsed = RBN * kCB * 16 / 32;     // relu-mask words this tile height fills (of kMaskWords)
+  // per-tile opaque copies of the thread ids: whatever is derived from them (store / load addresses of every phase) is
+  // computed inside the tile instead of being hoisted out of the persistent loop into registers that stay live through
+  // the GEMMs
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
   const int C = rgb_channels(deg);
   const float* __restrict__ bias = pk + fwd_bias_off(deg);
   const float* arow1 = lds + (lane & 31) * kLDA + (lane >> 5) * 4;
@@ -489,7 +494,15 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[r][c][i] = bl[c];
     const int wp = layer_wp(l);
-    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);
+    if (SAVE && l > 0) {
+      // the previous layer's activations leave for HBM during the GEMM that reads them (TileCopy)
+      int lane_c = lane;
+      asm volatile("" : "+v"(lane_c));   // the copy's lane constants are derived here, not hoisted over the posenc phase
+      const TileCopy tc = make_tile_copy<RBN>(lds, acts + (int64_t)(l - 1) * M * kW, row0, M, wave, lane_c, true);
+      gemm_lds_packed<RBN, kCB, true>(arow, wimg, wp, 32, 8 * 64, acc, bfrag, &tc);
+    } else {
+      gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);
+    }
     if (l == 5) {
       // skip connection (model_utils.py:70-71): x = concat([h4, inputs]) -> the 64 encoded
       // columns are a second K segment; the encoding is recomputed into the consumed tile.
@@ -544,10 +557,11 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
       uint32_t* mp = mask + ((slot * kDepth + l) * kMlpThreads + tid_e) * kMaskWords;
 #pragma unroll
       for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];
-      // this wave's 32 columns leave for HBM right behind its LDS writes (no barrier in between)
-      // (the forward kernel keeps this burst: copying the columns during the next GEMM, as the backward kernel does,
-      // measured 2.3 % slower here -- 4.15 vs 4.06 ms -- while it makes the backward kernel 3.2 % faster)
-      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);
+      // layers 0..6 leave for HBM during the next layer's GEMM (TileCopy above: 4.08 -> 3.99 ms per launch; a first attempt
+      // measured 2.3 % SLOWER because the copy's lane constants were hoisted out of the persistent tile loop and pushed the
+      // kernel into spills -- the per-tile opaque thread id at the top of this function is what makes it pay); only the last
+      // layer has no trunk GEMM behind it: its 32 columns leave right behind this wave's LDS writes (no barrier in between)
+      if (l == kDepth - 1) store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);
     }
     lds_barrier();
   }

@@ -158,7 +158,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* xa = &xs[buf][(lane >> 5) * KIN + (wr * RB) * 32 + (lane & 31)];
     const float* zb = &zs[buf][(lane >> 5) * NTILE + (wc * CB) * 32 + (lane & 31)];
     // (A chunk staged as [32-column block][row][32 columns], which turns every operand read into ds_read2st64_b32 immediates
-    // off ONE base register -- 10 instead of 18 VALU per 64 MFMAs -- measured 0.65 % slower per step, round 3: not kept.)
+    // off ONE base register -- 10 instead of 18 VALU per 64 MFMAs -- measured 0.65 % slower per step, round 3: not kept.
+    // Reading through volatile address_space(3) pointers -- every read a ds_read_b32 with a 16-bit immediate, NO vector ALU
+    // between the 64 MFMAs of a chunk, but 48 LDS instructions instead of 24 -- measured 0.8 % slower for this kernel
+    // (3.537 -> 3.565 ms): with two workgroups per CU the other workgroup's MFMAs fill the slots the v_adds cost.)
     // operands of k-step s+1 are read from LDS before the MFMAs of k-step s (order pinned: hipcc
     // otherwise sinks every ds_read to just before its use and waits lgkmcnt(0) every 4 MFMAs)
     float a0[RB], b0[CB], a1[RB], b1[CB];

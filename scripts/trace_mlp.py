@@ -45,16 +45,16 @@ def patch(src):
                   "float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,\n                                         int wave, unsigned long long* s_trace, int& s_tn, bool trace_on) {", 1)
     s = s.replace("  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();",
                   "  { const int l = 15; STAMP(14); }\n  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();\n  { const int l = 15; STAMP(15); }", 1)
-    s = s.replace("    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);",
-                  "    STAMP(0);\n    gemm_lds_packed<RBN, kCB>(arow, wimg, wp, l == 0 ? 8 : 32, 8 * 64, acc, bfrag);\n    if (l != 5) STAMP(1);", 1)
+    s = s.replace("    if (SAVE && l > 0) {\n      // the previous layer's activations leave", "    STAMP(0);\n    if (SAVE && l > 0) {\n      // the previous layer's activations leave", 1)
+    s = s.replace("    if (l == 5) {\n      // skip connection", "    if (l != 5) STAMP(1);\n    if (l == 5) {\n      // skip connection", 1)
     s = s.replace("      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n    }",
                   "      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n      STAMP(1);\n    }", 1)
     s = s.replace("    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite\n    // re-derive the lane ids",
                   "    lds_barrier();  // every wave has consumed the columns this wave is about to rewrite\n    STAMP(2);\n    // re-derive the lane ids", 1)
-    s = s.replace("      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      // (the forward kernel keeps this burst",
-                  "      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      STAMP(3);\n      // (the forward kernel keeps this burst", 1)
-    s = s.replace("      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n    }\n    lds_barrier();\n  }",
-                  "      store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n  }", 1)
+    s = s.replace("      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      // layers 0..6 leave for HBM",
+                  "      for (int w = 0; w < kWordsUsed; ++w) mp[w] = mw[w];\n      STAMP(3);\n      // layers 0..6 leave for HBM", 1)
+    s = s.replace("      if (l == kDepth - 1) store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n    }\n    lds_barrier();\n  }",
+                  "      if (l == kDepth - 1) store_wave_cols<RBN>(lds, acts + (int64_t)l * M * kW, row0, M, wave, lane_e);\n      STAMP(4);\n    }\n    lds_barrier();\n    STAMP(5);\n  }", 1)
     # kernel: trace buffers + flush
     s = s.replace("  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)\n    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,\n                                  mask, tid, lane, wave);",
                   "  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];\n  __shared__ unsigned long long s_trace_all[2][1536];\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n  const bool trace_on = blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4);\n  unsigned long long* s_trace = s_trace_all[wave >> 2];\n  int s_tn = 0;\n  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x) {\n    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,\n                                  mask, tid, lane, wave, s_trace, s_tn, trace_on);\n  }", 1)

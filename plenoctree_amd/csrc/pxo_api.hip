@@ -481,7 +481,7 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
     set_error("pxo_train_fwd_bwd: training runs in float32 only (mlp_precision must be PXO_MLP_F32)");
     return PXO_ERR_UNSUPPORTED;
   }
-  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  const int Nf = cfg->num_fine_samples;
   if (Nf > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
   hipStream_t s = (hipStream_t)stream;
   TrainWs t;

@@ -77,7 +77,6 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   // range read as zeros by the buffer bounds check -- no row predicates, no zero-selects and no 64-bit vector address
   // arithmetic in the loop (the predicated global_load form had 107 VALU instructions per 64 MFMAs, on the f32 lanes the
   // MFMAs run on).
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int64_t range_rows = r_end - r_begin;
   const __amdgpu_buffer_rsrc_t rsX =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + r_begin * KIN), 0, (int)(range_rows * KIN * 4), 0x00020000);

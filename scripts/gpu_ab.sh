@@ -2,6 +2,7 @@
 # A/B of kernel variants in one GPU session: bench.py (headline only) once per library in $LIBS (suffixes of
 # plenoctree_amd/libplenoctree_hip<suffix>.so; "" = the default build).
 set -u
+export PXO_ALLOW_VARIANT=1   # these sessions select variant libraries with PXO_LIB (plenoctree_amd/_lib.py refuses it otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 R=$PWD

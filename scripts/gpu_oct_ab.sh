@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of octree kernel variants: scripts/octree_bench.py once per library in $LIBS (suffixes of libplenoctree_hip<suffix>.so).
 set -u
+export PXO_ALLOW_VARIANT=1   # these sessions select variant libraries with PXO_LIB (plenoctree_amd/_lib.py refuses it otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 R=$PWD

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of split-precision forward variants: the x3 tests (optional) + bench.py's opt_in_bf16x3_inference record per library.
 set -u
+export PXO_ALLOW_VARIANT=1   # these sessions select variant libraries with PXO_LIB (plenoctree_amd/_lib.py refuses it otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 R=$PWD

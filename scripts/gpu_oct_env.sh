@@ -19,7 +19,7 @@ for e in ${ENVS:--}; do
 import json, sys
 try:
     d = json.load(open(f"gpurun_out/oenv_{sys.argv[2]}{sys.argv[1]}.json"))
-    print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if ("ms" in k or "sum" in k) and "tree" not in k and "sample" not in k})
+    print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if ("ms" in k or "sum" in k or "fraction" in k) and "tree" not in k and "sample" not in k})
 except Exception as ex:
     print("no result", ex)
 PY

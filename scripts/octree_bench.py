@@ -38,6 +38,7 @@ def main():
     p.add_argument("--cams", type=int, default=8)
     p.add_argument("--basis", type=int, default=16, help="SH basis_dim of the tree data (16 or 25)")
     p.add_argument("--gw-only", action="store_true", help="stop after grid_weight_render (A/B of that kernel)")
+    p.add_argument("--hard", action="store_true", help="exact zeros outside the spheres (as a trained, relu'd density has) instead of fuzzy tails")
     a = p.parse_args()
     from plenoctree_amd import build, octree_ops as oops
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
@@ -53,12 +54,15 @@ def main():
     for c, r in (((0.0, 0.0, 0.0), 0.6), ((0.7, 0.3, 0.2), 0.3), ((-0.5, -0.4, 0.5), 0.35)):
         d2 = (ax[:, None, None] - c[0]) ** 2 + (ax[None, :, None] - c[1]) ** 2 + (ax[None, None, :] - c[2]) ** 2
         sig += 40.0 * torch.sigmoid((r - d2.sqrt()) * 60.0)
+    if a.hard:
+        sig = torch.where(sig > 1.0, sig, torch.zeros_like(sig))
     sig = sig.reshape(-1).contiguous()
+    out_occ = float((sig > 0).float().mean())
     W = H = a.size
     focal = 0.5 * W / np.tan(0.5 * 0.6911112)
     rs = np.random.RandomState(7)
     cams = torch.from_numpy(np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(a.cams)])).to(dev)
-    out = {"basis_dim": K, "depth": depth, "reso": reso, "image": [H, W], "step_size": a.step, "cams": a.cams}
+    out = {"sigma_positive_fraction": out_occ, "basis_dim": K, "depth": depth, "reso": reso, "image": [H, W], "step_size": a.step, "cams": a.cams}
 
     opts = oops.render_opts(a.step)
     wt = torch.zeros(reso ** 3, device=dev)

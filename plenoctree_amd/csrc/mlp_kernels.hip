@@ -156,12 +156,18 @@ __device__ __forceinline__ void grid_point(const GridSpec& g, int64_t n, float& 
 
 // writes posenc of the tile's 32*RBN points into lds[:, 0:64]; GRID = false (the training kernels: points always come from
 // memory) keeps the 12 GridSpec scalars out of the kernel's SGPR budget
-template <int RBN, bool GRID = true>
+// KEEP: also returns this thread's kColsPer values (the forward-only kernels put them back for the skip layer with
+// posenc_restore instead of evaluating 16 sinf per point a second time)
+template <int RBN> struct EncGeom {
+  static constexpr int kRows = 32 * RBN;
+  static constexpr int kParts = kMlpThreads / kRows;     // 4 (full tile) / 8 (half tile)
+  static constexpr int kColsPer = kEncPad / kParts;      // 16 / 8
+};
+template <int RBN, bool GRID = true, bool KEEP = false>
 __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float* __restrict__ pts,
-                                            const GridSpec& grid, int64_t row0, int64_t M, int tid) {
-  constexpr int kRows = 32 * RBN;
-  constexpr int kParts = kMlpThreads / kRows;     // 4 (full tile) / 8 (half tile)
-  constexpr int kColsPer = kEncPad / kParts;      // 16 / 8
+                                            const GridSpec& grid, int64_t row0, int64_t M, int tid,
+                                            float (*keep)[EncGeom<RBN>::kColsPer] = nullptr) {
+  constexpr int kRows = EncGeom<RBN>::kRows, kColsPer = EncGeom<RBN>::kColsPer;
   const int row = tid % kRows, part = tid / kRows;
   const int64_t grow = row0 + row;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -172,8 +178,17 @@ __device__ __forceinline__ void posenc_tile(float* __restrict__ lds, const float
 #pragma unroll 4
   for (int i = 0; i < kColsPer; ++i) {
     const int col = part * kColsPer + i;
-    lds[row * kLDA + col] = enc_value(p0, p1, p2, col);
+    const float e = enc_value(p0, p1, p2, col);
+    lds[row * kLDA + col] = e;
+    if (KEEP) (*keep)[i] = e;
   }
+}
+template <int RBN>
+__device__ __forceinline__ void posenc_restore(float* __restrict__ lds, int tid, const float (&keep)[EncGeom<RBN>::kColsPer]) {
+  constexpr int kRows = EncGeom<RBN>::kRows, kColsPer = EncGeom<RBN>::kColsPer;
+  const int row = tid % kRows, part = tid / kRows;
+#pragma unroll
+  for (int i = 0; i < kColsPer; ++i) lds[row * kLDA + part * kColsPer + i] = keep[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -462,7 +477,8 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   const WImage wimg = make_wimage(pk, fwd_image_floats(deg), lane);
   const bool full = row0 + kRows <= M;
   lds_barrier();   // previous tile's head GEMM has consumed the LDS tile
-  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);
+  float enc_keep[EncGeom<RBN>::kColsPer];
+  posenc_tile<RBN, !SAVE, !SAVE>(lds, pts, grid, row0, M, tid, &enc_keep);
   lds_barrier();
   if (SAVE) {  // coalesced copy of the encoded tile (layer-0 / layer-5 weight gradients)
 #pragma unroll
@@ -520,7 +536,7 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
           *reinterpret_cast<f32x4*>(lds + row * kLDA + c4 * 4) = v;
         }
       } else {
-        posenc_tile<RBN>(lds, pts, grid, row0, M, tid);
+        posenc_restore<RBN>(lds, tid, enc_keep);
       }
       lds_barrier();
       gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);

@@ -43,8 +43,8 @@ def patch(src):
     # forward tile: trace state is handed in through two extra parameters
     s = s.replace("float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,\n                                         int wave) {",
                   "float* __restrict__ enc_out, uint32_t* __restrict__ mask, int tid, int lane,\n                                         int wave, unsigned long long* s_trace, int& s_tn, bool trace_on) {", 1)
-    s = s.replace("  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();",
-                  "  { const int l = 15; STAMP(14); }\n  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  posenc_tile<RBN, !SAVE>(lds, pts, grid, row0, M, tid);\n  lds_barrier();\n  { const int l = 15; STAMP(15); }", 1)
+    s = s.replace("  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  float enc_keep[EncGeom<RBN>::kColsPer];\n  posenc_tile<RBN, !SAVE, !SAVE>(lds, pts, grid, row0, M, tid, &enc_keep);\n  lds_barrier();",
+                  "  { const int l = 15; STAMP(14); }\n  lds_barrier();   // previous tile's head GEMM has consumed the LDS tile\n  float enc_keep[EncGeom<RBN>::kColsPer];\n  posenc_tile<RBN, !SAVE, !SAVE>(lds, pts, grid, row0, M, tid, &enc_keep);\n  lds_barrier();\n  { const int l = 15; STAMP(15); }", 1)
     s = s.replace("    if (SAVE && l > 0) {\n      // the previous layer's activations leave", "    STAMP(0);\n    if (SAVE && l > 0) {\n      // the previous layer's activations leave", 1)
     s = s.replace("    if (l == 5) {\n      // skip connection", "    if (l != 5) STAMP(1);\n    if (l == 5) {\n      // skip connection", 1)
     s = s.replace("      gemm_lds_packed<RBN, kCB>(arow, wimg, wp + 32 * 8 * 64, 8, 8 * 64, acc, bfrag);\n    }",

@@ -99,7 +99,9 @@ int pxo_tree_relu_sigma(float* data, int64_t n_cells, int data_dim, void* stream
  * the dense sigma grid [reso^3] and keeps, per voxel, the maximum compositing weight
  * light * (1 - exp(-dt * sigma)).  grid_weight [reso^3] must be zero-initialised by the caller for the
  * first call; successive calls accumulate the maximum (torch.max over cameras, :206-212).
- * ws: pxo_grid_weight_workspace_bytes(reso) bytes (brick-ordered copies of the grid and the weights). */
+ * ws: pxo_grid_weight_workspace_bytes(reso) bytes (brick-ordered copies of the grid and the weights, and the count of
+ * voxels above sigma_thresh by which the launch picks its marcher on the device: slab-staged for dense grids, per-sample
+ * for sparse ones - same samples, same arithmetic, bit-identical weights either way; the call stays asynchronous). */
 int pxo_grid_weight_workspace_bytes(int reso, size_t* bytes);
 int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx,
                            float fy, int width, int height, const PxoRenderOpts* opts, const float offset[3],

@@ -43,7 +43,10 @@ def area_resize(image, out_h, out_w):
         return w
     img = np.asarray(image, np.float32)
     wy, wx = weights(img.shape[0], out_h), weights(img.shape[1], out_w)
-    return np.einsum("yi,ijc,xj->yxc", wy, img.astype(np.float64), wx).astype(np.float32)
+    # separable: rows first, then columns (two matrix products; a three-operand einsum without a contraction path is
+    # one loop over y*x*i*j*c -- minutes per 800 x 800 image)
+    rows = np.tensordot(wy, img.astype(np.float64), axes=(1, 0))          # [out_h, W, C]
+    return np.einsum("yjc,xj->yxc", rows, wx).astype(np.float32)
 
 
 def analytic_scene_rgb(origins, directions, white_bkgd=True):

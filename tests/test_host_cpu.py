@@ -154,6 +154,24 @@ def test_nsvf_loader_on_a_synthetic_directory(tmp_path):
     assert (half.h, half.w) == (3, 4) and half.focal == pytest.approx(15.5)
 
 
+def test_area_resize_full_size_is_block_mean_and_fast():
+    """The cv2.INTER_AREA stand-in at the reference's real size (800 x 800 RGBA -> 400 x 400, datasets.py:208-212): equal to
+    the 2 x 2 block mean, a non-integer ratio keeps the image mean, and an image takes well under a second (a naive
+    three-operand einsum took minutes)."""
+    import time
+    from plenoctree_amd.nerf_sh.nerf.datasets import area_resize
+    rs = np.random.RandomState(3)
+    img = rs.rand(800, 800, 4).astype(np.float32)
+    t0 = time.perf_counter()
+    half = area_resize(img, 400, 400)
+    dt = time.perf_counter() - t0
+    want = img.reshape(400, 2, 400, 2, 4).astype(np.float64).mean(axis=(1, 3))
+    np.testing.assert_allclose(half, want, atol=1e-6)
+    assert dt < 5.0, f"area_resize of one 800 x 800 image took {dt:.1f} s"
+    odd = area_resize(img, 300, 500)                                  # 800/300 is not an integer
+    assert odd.shape == (300, 500, 4) and abs(float(odd.mean()) - float(img.mean())) < 1e-5
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run, one rank per GPU
     (rendezvous on 127.0.0.1); with too few devices it says so instead of asking for a wrapper."""

@@ -24,10 +24,16 @@ Parity status
 * loss_fn's VALUE and Stats are PINNED against the reference's own train_step
   (nerf_sh/train.py:51-121) run through the shim with value_and_grad evaluating
   the function only (tests/golden/train_loss.npz).
-* the GRADIENT (jax AD) and Adam (flax.optim) remain "PARITY UNPINNED": they
-  cannot be imported here, and the reference ships no tests or vectors for them.  They
-  are restated line by line from the cited reference lines and pinned only by
-  closed-form known answers (tests/test_oracle_known_answers.py).
+* the GRADIENT of loss_fn is PINNED against reverse-mode AD through the reference's own
+  loss_fn body: tests/golden/make_golden_grad.py imports nerf_sh/train.py, models.py,
+  model_utils.py and sh.py from the reference with TORCH standing in for jax.numpy
+  (jax.value_and_grad = torch autograd, lax.stop_gradient = detach) and stores the
+  float64 gradient of a 24-ray step with sparsity and weight-decay terms in
+  tests/golden/train_grad.npz; `loss_and_grad` reproduces it to the fixture's storage
+  rounding, leaf by leaf (tests/test_oracle_golden.py).
+* Adam (flax.optim) remains "PARITY UNPINNED": flax cannot be imported here and the
+  reference ships no vectors for it; `adam_update` restates the published rule and is
+  pinned only by closed-form known answers (tests/test_oracle_known_answers.py).
 * flax.optim.Adam is third-party (flax>=0.3.1, environment.yml:19; call sites
   nerf_sh/nerf/models.py:44, nerf_sh/train.py:119); its published update rule
   is restated in `adam_update`.

@@ -1,0 +1,249 @@
+"""The HIP path (through the C ABI) against vectors PRODUCED BY REFERENCE CODE -- no oracle in between.
+
+Every expected value below was written by tests/golden/make_golden.py / make_golden_grad.py, which import the
+reference's own modules (nerf_sh/nerf/model_utils.py, models.py, sh.py, train.py, octree/nerf/utils.py) and execute their
+function bodies.  One test per SURVEY 8(a) row:
+
+  F1  sample_along_rays + cast_rays   model_utils.py:97-142    pxo_sample_along_rays      model_utils.npz
+  F5  eval_sh                         sh.py:54-109             pxo_shade_composite_fwd    eval_sh.npz
+  F6  sigmoid / relu                  models.py:280-281        pxo_shade_composite_fwd    eval_sh.npz / model_utils.npz
+  F7  volumetric_rendering            model_utils.py:176-222   pxo_shade_composite_fwd    model_utils.npz
+  F8  piecewise_constant_pdf          model_utils.py:225-286   pxo_sample_pdf             model_utils.npz
+  F9  sample_pdf (sort, cast_rays)    model_utils.py:289-314   pxo_sample_pdf             model_utils.npz
+  R1  NerfModel.__call__              models.py:216-348        pxo_render_fwd             nerf_model.npz
+  L1  loss_fn (Stats)                 train.py:68-114          pxo_train_fwd_bwd          train_loss.npz
+  G1  value_and_grad(loss_fn)         train.py:116             pxo_train_fwd_bwd          train_grad.npz
+  H1  generate_rays                   utils.py:545-589         pxo_generate_rays          generate_rays.npz / nerf_sh_utils.npz
+(F2 posenc and F3 MLP against reference output: tests/test_gpu_parity.py::test_posenc_golden_and_oracle,
+test_eval_points_golden.)  Tolerances are the numbers written next to each comparison.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+from _helpers import _gpu, _ops, pxo_cfg  # noqa: E402
+
+C0 = 0.28209479177387814
+
+
+def _params_flat(gw, shift=0.0):
+    params = [[(torch.tensor(gw[f"MLP_{mi}.Dense_{li}.kernel"]), torch.tensor(gw[f"MLP_{mi}.Dense_{li}.bias"]))
+               for li in range(10)] for mi in range(2)]
+    flat = O.flatten_params(params)
+    n = flat.numel() // 2
+    if shift:
+        for mi in range(2):               # sigma-head bias (Dense_8), float32 add as in make_golden_grad.py
+            flat[(mi + 1) * n - 48 - 48 * 256 - 1] += shift
+    return flat
+
+
+def _allclose(name, got, want, rtol, atol):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=name)
+
+
+def test_sample_along_rays_against_reference(golden_dir):
+    """F1.  z to 2 ulp of 6.0 (rtol 2e-6 / atol 1e-6), points to atol 4e-6 (|o| = 4, |z d| <= 6: one rounding each)."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "model_utils.npz"))
+    o, d = torch.tensor(g["origins"], device=dev), torch.tensor(g["directions"], device=dev)
+    t_rand = torch.tensor(g["t_rand"], device=dev)
+    for lindisp in (0, 1):
+        for randomized in (0, 1):
+            z, pts = ops.sample_along_rays(o, d, 64, 2.0, 6.0, t_rand if randomized else None, lindisp=bool(lindisp))
+            _allclose(f"z l{lindisp} r{randomized}", z, g[f"z_l{lindisp}_r{randomized}"], 2e-6, 1e-6)
+            _allclose(f"pts l{lindisp} r{randomized}", pts, g[f"pts_l{lindisp}_r{randomized}"], 2e-6, 4e-6)
+
+
+def test_eval_sh_sigmoid_against_reference(golden_dir):
+    """F5 + F6.  eval_sh.npz: coefficients [29 rays, 5 samples, 3, K], unit dirs, and the reference's eval_sh output for
+    sh_deg 0..4.  The kernel evaluates SH inside the compositing, so each sample is isolated by making it the only
+    opaque one (sigma = 1e9 there, <= 0 elsewhere; black background): comp_rgb = sigmoid(eval_sh(sample j)) * 1.
+    atol 2e-6 on a value in (0,1): sigmoid' <= 1/4, K <= 25 products of O(1) each rounded once."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "eval_sh.npz"))
+    dirs = torch.tensor(g["dirs"], device=dev)
+    B, S = 29, 5
+    z = torch.linspace(2.0, 6.0, S, device=dev).expand(B, S).contiguous()
+    for deg in range(5):
+        K = (deg + 1) ** 2
+        cfg = ops.make_cfg(sh_deg=deg, white_bkgd=0, num_coarse_samples=S, num_fine_samples=0)
+        raw_rgb = torch.tensor(g[f"sh_{deg}"], device=dev).reshape(B * S, 3 * K).contiguous()   # [.., c, k] channel-major
+        want = 1.0 / (1.0 + np.exp(-g[f"res_{deg}"].astype(np.float64)))                           # rgb_activation
+        for j in range(S):
+            raw_sigma = torch.full((B, S), -1.0, device=dev)
+            raw_sigma[:, j] = 1e9
+            comp, disp, acc, w = ops.shade_composite_fwd(cfg, raw_rgb, raw_sigma.reshape(-1).contiguous(), z, dirs, dirs)
+            _allclose(f"eval_sh deg {deg} sample {j}", comp, want[:, j], 0, 2e-6)
+            _allclose("acc", acc, np.ones(B, np.float32), 0, 1e-6)
+
+
+def test_volumetric_rendering_against_reference(golden_dir):
+    """F7 (+ F6).  model_utils.npz holds rgb in (0,1) and sigma >= 0 AFTER the activations; the kernel takes raw values, so
+    it is run with sh_deg 0 on raw = logit(rgb) / C0 (sigmoid(C0 * raw) = rgb to 1 ulp) and raw_sigma = sigma
+    (relu is the identity on sigma >= 0; the empty ray and the opaque surface of the fixture are kept).
+    weights / comp / acc: rtol 1e-5, atol 1e-6 (64-term products and sums in float32); disp = acc/depth: rtol 2e-5."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "model_utils.npz"))
+    rgb, sigma = g["vr_rgb"].astype(np.float64), g["vr_sigma"]
+    B, S = sigma.shape[:2]
+    raw = (np.log(rgb) - np.log1p(-rgb)) / C0
+    raw_rgb = torch.tensor(raw.astype(np.float32), device=dev).reshape(B * S, 3).contiguous()
+    raw_sigma = torch.tensor(sigma, device=dev).reshape(-1).contiguous()
+    z = torch.tensor(g["z_l0_r1"], device=dev)
+    d = torch.tensor(g["directions"], device=dev)
+    v = d / d.norm(dim=-1, keepdim=True)
+    for white in (0, 1):
+        cfg = ops.make_cfg(sh_deg=0, white_bkgd=white, num_coarse_samples=S, num_fine_samples=0)
+        comp, disp, acc, w = ops.shade_composite_fwd(cfg, raw_rgb, raw_sigma, z, d, v)
+        _allclose("weights", w, g[f"vr_weights_w{white}"], 1e-5, 1e-7)
+        _allclose("comp", comp, g[f"vr_comp_w{white}"], 1e-5, 2e-6)
+        _allclose("acc", acc, g[f"vr_acc_w{white}"], 1e-5, 1e-6)
+        _allclose("disp", disp, g[f"vr_disp_w{white}"], 2e-5, 1e-6)
+        assert float(acc[0]) == 0.0 and float(disp[0]) == float(np.float32(1e10))      # the guarded division, bit for bit
+
+
+def test_sample_pdf_against_reference(golden_dir):
+    """F8 + F9.  The reference's float32 inverse CDF against the kernel's (float64 running sum rounded once per knot,
+    DESIGN 2: a deliberate departure that is closer to exact).  A sample inside a bin of probability mass dm and width
+    w moves by w * eps / dm per ulp of the cdf, so: |dz| <= 1e-5 + 16 eps w / dm, never more than one bin, and at least
+    98 % of the samples within 1e-5 (same statement the oracle is held to on the CPU).  Sorted, 192 values, coarse values
+    copied bit for bit; points = o + z d to atol 5e-6."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "model_utils.npz"))
+    o, d = torch.tensor(g["origins"], device=dev), torch.tensor(g["directions"], device=dev)
+    zc = torch.tensor(g["z_l0_r1"], device=dev)
+    B, Nc = zc.shape
+    w_inner = g["pdf_weights"]                                    # weights[..., 1:-1]; row 2 is all zero (eps padding)
+    w_full = np.zeros((B, Nc), np.float32); w_full[:, 1:-1] = w_inner
+    bins = g["pdf_bins"].astype(np.float64)
+    wd = w_inner.astype(np.float64)
+    wsum = wd.sum(-1, keepdims=True); pad = np.maximum(0.0, 1e-5 - wsum)
+    pdf = (wd + pad / wd.shape[-1]) / (wsum + pad)
+    width = bins[:, 1:] - bins[:, :-1]
+    for randomized in (0, 1):
+        u = torch.tensor(g["pdf_u"], device=dev) if randomized else None
+        z, pts = ops.sample_pdf(zc, torch.tensor(w_full, device=dev), o, d, 128, u)
+        z_np = z.cpu().numpy()
+        want = g[f"sample_pdf_z_r{randomized}"]
+        assert z_np.shape == (B, 192) and bool((z_np[:, 1:] >= z_np[:, :-1]).all())
+        for b in range(B):                                         # every coarse value is present bit for bit
+            assert np.isin(g["z_l0_r1"][b], z_np[b]).all()
+        err = np.abs(z_np.astype(np.float64) - want)
+        assert np.mean(err > 1e-5) < 0.02, np.mean(err > 1e-5)
+        for b, e in zip(*np.nonzero(err > 1e-5)):
+            k = int(np.clip(np.searchsorted(bins[b], want[b, e], side="right") - 1, 0, Nc - 3))
+            lim = 1e-5 + 16 * 1.2e-7 * width[b, k] / max(pdf[b, k], 1e-12)
+            assert err[b, e] <= min(lim, 1.001 * width[b, k]), (b, e, err[b, e], lim, pdf[b, k])
+        got_pts = pts.cpu().numpy()
+        np.testing.assert_allclose(got_pts, g["origins"][:, None] + z_np[..., None] * g["directions"][:, None], rtol=0, atol=5e-6)
+        perr = np.abs(got_pts - g[f"sample_pdf_pts_r{randomized}"])
+        assert np.mean(perr > 2e-5) < 0.02 and perr.max() < 4e-3
+
+
+def test_render_fwd_against_reference_nerf_model_call(golden_dir):
+    """R1.  nerf_model.npz = the reference's NerfModel.__call__ on the weights of eval_points_sh16.npz (6 rays that see
+    empty and opaque space), randomized and deterministic.  rgb / acc atol 2e-5 (north_star's 1e-4 dB corresponds to
+    ~1e-5 relative colour error at these values), disp rtol 2e-3 (acc / depth on nearly empty rays)."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "nerf_model.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    cfg = O.Cfg()
+    pcfg = pxo_cfg(ops, cfg)
+    flat = _params_flat(gw).to(dev)
+    n = flat.numel() // 2
+    pk = [ops.pack_weights(pcfg, flat[i * n:(i + 1) * n].contiguous(), need_bwd=False)[0] for i in range(2)]
+    o, d, v = [torch.tensor(g[k], device=dev) for k in ("origins", "directions", "viewdirs")]
+    for r in (0, 1):
+        out = ops.render_fwd(pcfg, pk[0], pk[1], o, d, v, randomized=bool(r),
+                             t_rand=torch.tensor(g["t_rand"], device=dev) if r else None,
+                             u=torch.tensor(g["u"], device=dev) if r else None)
+        for lvl, (rgb, disp, acc) in zip(("coarse", "fine"), out):
+            _allclose(f"rgb {lvl} r{r}", rgb, g[f"rgb_{lvl}_r{r}"], 0, 2e-5)
+            _allclose(f"acc {lvl} r{r}", acc, g[f"acc_{lvl}_r{r}"], 0, 2e-5)
+            _allclose(f"disp {lvl} r{r}", disp, g[f"disp_{lvl}_r{r}"], 2e-3, 1e-6)
+
+
+def _train_once(ops, dev, g, gw, shift, n_sp, wd):
+    cfg = O.Cfg(sparsity_npoints=n_sp, weight_decay_mult=wd)
+    pcfg = pxo_cfg(ops, cfg)
+    flat = _params_flat(gw, shift).to(dev)
+    n = flat.numel() // 2
+    packed = [ops.pack_weights(pcfg, flat[i * n:(i + 1) * n].contiguous()) for i in range(2)]
+    o, d, v, px = [torch.tensor(g[k], device=dev) for k in ("origins", "directions", "viewdirs", "pixels")]
+    sp = (-1.5 + 3.0 * torch.tensor(g["sp_u"])).to(dev)           # random.uniform(key, minval=-r, maxval=r), train.py:79
+    grads = torch.zeros_like(flat); stats = torch.zeros(6, device=dev)
+    ws = torch.empty(ops.train_workspace_bytes(pcfg, o.shape[0]), dtype=torch.uint8, device=dev)
+    ops.train_fwd_bwd(pcfg, flat, packed, o, d, v, px, grads, stats, ws, randomized=True,
+                      t_rand=torch.tensor(g["t_rand"], device=dev), u=torch.tensor(g["u"], device=dev), sp_points=sp)
+    torch.cuda.synchronize()
+    from plenoctree_amd.nerf_sh.nerf import utils
+    return cfg, dict(zip(utils.Stats._fields, stats.cpu().tolist())), grads.cpu()
+
+
+def test_train_stats_against_reference_loss_fn(golden_dir):
+    """L1.  train_loss.npz: Stats of the reference's own train_step (500 sparsity points, weight_decay_mult 0.1).
+    loss / loss_c / weight_l2 / psnr / psnr_c rel 2e-5; loss_sp rel 5e-3 (it is 1e-3 * (1 - mean exp(-0.05 relu sigma)):
+    a difference of nearly equal numbers)."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "train_loss.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    _, st, _ = _train_once(ops, dev, g, gw, 0.0, int(g["sparsity_npoints"]), float(g["weight_decay_mult"]))
+    for k in ("loss", "loss_c", "weight_l2", "psnr", "psnr_c"):
+        assert st[k] == pytest.approx(float(g[k]), rel=2e-5), (k, st[k], float(g[k]))
+    assert st["loss_sp"] == pytest.approx(float(g["loss_sp"]), rel=5e-3, abs=1e-9)
+
+
+def test_train_gradient_against_reference_autograd(golden_dir):
+    """G1.  train_grad.npz: float64 reverse-mode AD through the reference's loss_fn body (make_golden_grad.py), 24 rays,
+    500 sparsity points, weight decay on.  Bounds, relative L2 over each MLP's sub-arena:
+      MLP_0 (coarse: positions do not depend on the parameters)                  <= 3e-4   (float32 GEMM chains)
+      MLP_1 (fine: positions from the float32 inverse CDF, condition number ~1e4) <= 3 x the reference's OWN float32
+             evaluation's distance from its float64 one, which the fixture records (8.8e-4)
+    and every one of the 40 leaves within 10x its MLP's bound (a wrong small leaf cannot hide in the norm).
+    Stats against the float64 run: rel 2e-5."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "train_grad.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    cfg, st, grad = _train_once(ops, dev, g, gw, float(g["sigma_bias_shift"]), int(g["sparsity_npoints"]),
+                                float(g["weight_decay_mult"]))
+    want = torch.tensor(g["grad"]).double()
+    got = grad.double()
+    n = want.numel() // 2
+    ref32 = float(g["grad_f32_vs_f64_rel_l2"])
+    bounds = (3e-4, 3 * ref32)
+    rels = [float((got[i * n:(i + 1) * n] - want[i * n:(i + 1) * n]).norm() / want[i * n:(i + 1) * n].norm()) for i in range(2)]
+    print(f"HIP vs reference-autograd gradient: MLP_0 rel L2 {rels[0]:.2e}, MLP_1 {rels[1]:.2e} "
+          f"(reference f32 vs f64 over both: {ref32:.2e})")
+    assert rels[0] <= bounds[0] and rels[1] <= bounds[1], rels
+    off = 0
+    for mi in range(2):
+        for li, (fi, fo) in enumerate(O.layer_shapes(cfg)):
+            for cnt in (fi * fo, fo):
+                a, b = got[off:off + cnt], want[off:off + cnt]
+                assert float((a - b).norm()) <= 10 * bounds[mi] * float(b.norm()) + 1e-9, (mi, li, cnt)
+                off += cnt
+    for k in ("loss", "loss_c", "weight_l2", "psnr", "psnr_c"):
+        assert st[k] == pytest.approx(float(g[k + "_f64"]), rel=2e-5), k
+
+
+def test_generate_rays_against_reference(golden_dir):
+    """H1.  generate_rays of octree/nerf/utils.py (generate_rays.npz) and of nerf_sh/nerf/utils.py (nerf_sh_utils.npz) on 3
+    cameras of 9 x 7 pixels: origins bit-exact, directions / viewdirs rtol 1e-6 + atol 1e-6."""
+    ops = _ops(); dev = _gpu()
+    g = np.load(os.path.join(golden_dir, "generate_rays.npz"))
+    g2 = np.load(os.path.join(golden_dir, "nerf_sh_utils.npz"))
+    w, h, focal = int(g["w"]), int(g["h"]), float(g["focal"])
+    for ci, c2w in enumerate(g["c2w"]):
+        o, d, v = ops.generate_rays(torch.tensor(c2w, device=dev), w, h, focal)
+        for want_o, want_d, want_v in ((g["origins"], g["directions"], g["viewdirs"]),
+                                       (g2["rays_origins"], g2["rays_directions"], g2["rays_viewdirs"])):
+            np.testing.assert_array_equal(o.cpu().numpy(), want_o[ci].reshape(-1, 3))
+            _allclose("directions", d, want_d[ci].reshape(-1, 3), 1e-6, 1e-6)
+            _allclose("viewdirs", v, want_v[ci].reshape(-1, 3), 1e-6, 1e-6)

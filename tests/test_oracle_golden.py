@@ -201,6 +201,56 @@ def test_loss_matches_the_reference_train_step(golden_dir):
     assert float(total) == pytest.approx(float(g["total"]), rel=2e-5)
 
 
+def _train_grad_inputs(g, gw, dtype):
+    """Inputs of tests/golden/train_grad.npz in `dtype` (weights of eval_points_sh16.npz, sigma-head biases + shift)."""
+    cfg = O.Cfg(sparsity_npoints=int(g["sparsity_npoints"]), weight_decay_mult=float(g["weight_decay_mult"]))
+    params = _params_from_npz(gw, cfg)
+    flat = O.flatten_params(params)
+    n = flat.numel() // 2
+    for mi in range(2):                                   # Dense_8 bias = the float just before Dense_9's kernel + bias
+        flat[(mi + 1) * n - 48 - 48 * 256 - 1] += float(g["sigma_bias_shift"])
+    # the shift is applied in float32, as the fixture's generator did: the fine-pass gradient has a condition number of
+    # ~1e4 with respect to the coarse density (sample positions x 2^9 encoding frequencies), so a bias that differs in
+    # the 8th digit moves MLP_1's gradient by 1e-4 even in float64
+    flat = flat.to(dtype)
+    rays = O.Rays(*[torch.tensor(g[k]).to(dtype) for k in ("origins", "directions", "viewdirs")])
+    sp = -1.5 + 3.0 * torch.tensor(g["sp_u"]).to(dtype)    # random.uniform(key, minval=-r, maxval=r), train.py:79
+    return cfg, flat, rays, torch.tensor(g["pixels"]).to(dtype), torch.tensor(g["t_rand"]).to(dtype), torch.tensor(g["u"]).to(dtype), sp
+
+
+def test_gradient_against_the_references_loss_fn_under_autograd(golden_dir):
+    """tests/golden/train_grad.npz: reverse-mode AD (torch) through the REFERENCE'S OWN loss_fn body -- train.py:68-116
+    with models.py / model_utils.py / sh.py imported from the reference and torch standing in for jax.numpy
+    (tests/golden/make_golden_grad.py).  The oracle's jax.value_and_grad restatement must give the same gradient:
+    float64 against float64 to the fixture's storage rounding (it is kept as float32: 6e-8 per element), and in
+    float32 no further away than the reference's own float32 evaluation is (stored in the fixture)."""
+    g = np.load(os.path.join(golden_dir, "train_grad.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    want = torch.tensor(g["grad"]).double()
+    cfg, flat, rays, px, t_rand, u, sp = _train_grad_inputs(g, gw, torch.float64)
+    total, stats, grad = O.loss_and_grad(flat, rays, px, cfg, t_rand, u, sp)
+    rel = float((grad - want).norm() / want.norm())
+    assert rel < 2e-7, rel
+    assert float(want.norm()) == pytest.approx(float(g["grad_norm_f64"]), rel=1e-6)
+    # every leaf on its own (a wrong small leaf would hide in the global norm)
+    off = 0
+    for mi in range(2):
+        for li, (fi, fo) in enumerate(O.layer_shapes(cfg)):
+            for n in (fi * fo, fo):
+                a, b = grad[off:off + n], want[off:off + n]
+                assert float((a - b).norm()) <= 2e-7 * float(b.norm()) + 1e-12, (mi, li, n)
+                assert float(b.norm()) > 0, (mi, li, n)          # the loss reaches every leaf
+                off += n
+    for k in ("loss", "loss_c", "loss_sp", "weight_l2", "psnr", "psnr_c"):
+        assert float(stats[k]) == pytest.approx(float(g[k + "_f64"]), rel=1e-9), k
+    cfg, flat, rays, px, t_rand, u, sp = _train_grad_inputs(g, gw, torch.float32)
+    _, stats32, grad32 = O.loss_and_grad(flat, rays, px, cfg, t_rand, u, sp)
+    rel32 = float((grad32.double() - want).norm() / want.norm())
+    assert rel32 < 3 * float(g["grad_f32_vs_f64_rel_l2"]), (rel32, float(g["grad_f32_vs_f64_rel_l2"]))
+    for k in ("loss", "loss_c", "weight_l2"):
+        assert float(stats32[k]) == pytest.approx(float(g[k + "_f32"]), rel=2e-5), k
+
+
 def test_host_helpers_match_the_reference_utils(golden_dir):
     """pose_spherical (:656-685), learning_rate_decay (:483-515) and generate_rays (:545-589) of the reference's
     nerf_sh/nerf/utils.py, run through the shim."""

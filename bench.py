@@ -7,13 +7,21 @@ on N MI355X, BASELINE.json configs[1] (chair-shaped SH16 workload, 4096 rays per
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one full train_step (nerf_sh/train.py:51-121) on a synthetic batch: batch sampling,
-weight re-pack, coarse+fine forward, losses (incl. the 10k-point sparsity branch), backward,
-ONE RCCL all-reduce of the 4.05 MB gradient arena + stats (N > 1), Adam.  Rank 0 prints ONE JSON
-line; besides the headline it carries three more records of the other BASELINE configs:
-`tt_sh25` (configs[3] shape), `render_fwd` (the eval path) and `grid512` (configs[4]).
+coarse level forward + reverse, fine level forward + reverse (incl. the 10k-point sparsity branch),
+the gradient exchange (N > 1: two RCCL all-reduces, MLP_0's half of the 4.05 MB arena under the fine level,
+MLP_1's half + stats at the end), Adam + weight re-pack.  Rank 0 prints ONE JSON line; besides the headline it
+carries records of the other BASELINE configs and of the metric's second half:
+`converge` (eval PSNR on held-out 800x800 views after a fixed training budget), `strong512` (configs[2] strong-scaling
+shape), `tt_sh25` (configs[3] shape), `coarse64` (configs[0] shape: 64 coarse samples only), `render_fwd` (the eval
+path) and `grid512` (configs[4]).
+
+`--backend gloo` is a DRY RUN of this file's multi-rank control flow on CPU ranks for tests/test_bench_dry_run_cpu.py,
+which installs oracle-backed stand-ins for the HIP entry points first (the product has no CPU path: without the
+stand-ins every leg fails in ops._require_gpu).  Its numbers mean nothing.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -27,9 +35,11 @@ sys.path.insert(0, ROOT)
 
 FLOP_FWD_PER_ROW = {3: 1007104, 4: 1020928}          # GEMM MAC x2 per sample
 FLOP_TRAIN_PER_RAY = {3: 756.9e6, 4: 767.6e6}
+FLOP_TRAIN_PER_RAY_COARSE_ONLY = {3: 189.2e6, 4: 191.9e6}
 FLOP_RENDER_PER_RAY = {3: 257.8e6, 4: 261.4e6}
 FLOP_SIGMA_PER_POINT = 982528                        # trunk + sigma head only (131.9 TFLOP at 512^3)
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "bf16x3", "coarse64", "tt_sh25")
 
 
 def parse(argv=None):
@@ -41,7 +51,8 @@ def parse(argv=None):
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--preset", choices=["blender", "tt"], default="blender")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the tt_sh25 / render_fwd / grid512 records")
+    p.add_argument("--no-extras", action="store_true", help="headline only")
+    p.add_argument("--extras", default=",".join(ALL_EXTRAS), help="comma-separated subset of " + ",".join(ALL_EXTRAS))
     p.add_argument("--force-dist", action="store_true",
                    help="initialise RCCL and issue the per-step collectives even with one rank (exercises the "
                         "multi-GPU code path on a 1-GPU box)")
@@ -49,6 +60,16 @@ def parse(argv=None):
                    help="A/B only: no HIP events around the dominant kernels in the timed region (no roofline leg)")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
     p.add_argument("--cpu-steps", type=int, default=8)
+    p.add_argument("--converge-steps", type=int, default=2000, help="training budget of the `converge` record")
+    p.add_argument("--converge-views", type=int, default=2, help="held-out 800x800 views rendered for eval PSNR")
+    # sizes of the other records; the defaults are the BASELINE configs, the dry run passes small ones
+    p.add_argument("--strong-rays", type=int, default=512)
+    p.add_argument("--grid-reso", type=int, default=512)
+    p.add_argument("--eval-step", type=int, default=105,
+                   help="render_fwd / grid512 are evaluated on the parameters after exactly this many train steps")
+    p.add_argument("--image-factor", type=int, default=0, help="0 = 800x800 views (datasets.Synthetic)")
+    p.add_argument("--sparsity-npoints", type=int, default=None, help="dry run only (preset value otherwise)")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = CPU dry run (tests only)")
     return p.parse_args(argv)
 
 
@@ -58,7 +79,7 @@ def launch_command(n_gpus, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(a):
+def self_launch(a, argv):
     """`python bench.py --gpus N` without a launcher: one rank per GPU over RCCL."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < a.gpus:
@@ -68,28 +89,32 @@ def self_launch(a):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
-    return subprocess.call(launch_command(a.gpus, sys.argv[1:], port), env=env)
+    return subprocess.call(launch_command(a.gpus, argv, port), env=env)
 
 
-def flags_for(preset, batch):
+def flags_for(a, preset, batch, **over):
     from plenoctree_amd.nerf_sh.nerf import utils
     args = utils.define_flags().parse_args([])
     args.config = preset
     utils.update_flags(args)
     args.dataset = "synthetic"
     args.batch_size = batch
-    args.factor = 0                       # 800 x 800
+    args.factor = a.image_factor          # 0: 800 x 800
     args.train_dir = "/tmp/pxo_bench"
+    if a.sparsity_npoints is not None:
+        args.sparsity_npoints = a.sparsity_npoints
+    for k, v in over.items():
+        setattr(args, k, v)
     return args
 
 
-def cpu_baseline(args_ns, n_rays, n_steps, device):
+def cpu_baseline(a, args_ns, n_rays, n_steps, device):
     """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores
     on a bounded sample of the same workload: `n_rays` rays x (64+128) samples + 10k sparsity
     points, forward + backward + Adam, float32, torch CPU threads = all cores."""
     from oracle import nerf_oracle as O
     from plenoctree_amd.nerf_sh.nerf import datasets
-    cfg = O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far,
+    cfg = O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far, sparsity_npoints=args_ns.sparsity_npoints,
                 sparsity_length=args_ns.sparsity_length, sparsity_radius=args_ns.sparsity_radius)
     gen = torch.Generator().manual_seed(0)
     # the same feeder as the GPU legs (batches are drawn on the device and copied to the host before the clock starts)
@@ -135,50 +160,64 @@ def cpu_baseline(args_ns, n_rays, n_steps, device):
     return {"value": rps, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} train steps of {n_rays} rays x (64+128) samples + {cfg.sparsity_npoints} "
                       f"sparsity points, oracle/nerf_oracle.py (torch-CPU f32 restatement, not JAX), "
-                      f"{sum(times):.1f} s"}
+                      f"{sum(times):.1f} s on rank 0's host cores"}
 
 
 def hbm_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
-    (profiles/hbm_traffic.json; rocprofv3 cannot run inside the timed process).  None if absent."""
+    (profiles/hbm_traffic.json; rocprofv3 cannot run inside the timed process).  (None, None) if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            k = json.load(f)["kernels"][kernel]
-        return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+            doc = json.load(f)
+        k = doc["kernels"][kernel]
+        return (k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
+                "profiles/hbm_traffic.json (" + doc.get("source", "rocprofv3 --pmc passes of this command, committed") +
+                "); not measured inside this run")
     except Exception:
-        return None
+        return None, None
 
 
 class Job:
     """Rank context shared by the legs of the benchmark."""
 
     def __init__(self, a):
+        from plenoctree_amd import dist as pdist
         self.a = a
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(self.local_rank)
-        self.device = torch.device("cuda", self.local_rank)
+        self.cuda = a.backend == "nccl"
+        if self.cuda:
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device("cuda", self.local_rank)
+        else:
+            self.device = torch.device("cpu")
         self.dist = None
         self.ranks_seen = 1
-        if self.world > 1 or getattr(a, "force_dist", False):
-            import torch.distributed as dist_mod
-            self.dist = dist_mod
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            self.dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                         device_id=self.device)                    # RCCL over xGMI
+        self.pdist = pdist
+        if self.world > 1 or a.force_dist:
+            self.init_group()
             one = torch.ones(1, device=self.device)
             self.dist.all_reduce(one)
             self.ranks_seen = int(one.item())
 
-    def all_reduce_sum(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+    def init_group(self):
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29533 + os.getpid() % 2000))
+        kw = {"device_id": self.device} if self.cuda else {}
+        dist_mod.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)   # "nccl" = RCCL over xGMI
+        self.dist = dist_mod
+
+    def reducer(self):
+        """The per-step gradient exchange (two buckets, dist.GradReducer); forced on for one rank when a group exists."""
+        return self.pdist.GradReducer(self.comm(), self.device, force=self.dist is not None)
 
     def sync(self):
         if self.dist:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
         if not self.dist:
@@ -188,8 +227,7 @@ class Job:
         return float(t.item())
 
     def comm(self):
-        from plenoctree_amd import dist as pdist
-        return pdist.Comm(self.world, self.rank, self.local_rank, "nccl" if self.dist else None)
+        return self.pdist.Comm(self.world, self.rank, self.local_rank, self.a.backend if self.dist else None)
 
 
 def read_kernels(ops, deg):
@@ -211,10 +249,7 @@ def read_kernels(ops, deg):
     return kernels
 
 
-EVAL_STEP = 105      # render_fwd / grid512 are evaluated on the parameters after exactly this many train steps
-
-
-def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None):
+def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, **flag_over):
     """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats.
     snapshot_step: a copy of the parameters after exactly that many steps from the fixed-seed initialisation is kept
     (taken inside the run if it gets that far, by untimed extra steps otherwise), so that the records evaluated on
@@ -224,24 +259,25 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None):
     a = job.a
     if per_gpu is None:
         per_gpu = a.batch if a.scaling == "weak" else a.batch // job.world
-    args = flags_for(preset, per_gpu)
+    args = flags_for(a, preset, per_gpu, **flag_over)
     model, params = models.construct_nerf(args, job.device)
     state = models.TrainState(model.cfg, params)
     dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
+    reducer = job.reducer()
     snap = {}
 
     def one_step(step):
         batch = next(dataset)
         lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps)
         models.train_step(model, state, batch, lr, randomized=True, seed=(step << 8) | job.rank,
-                          world_size=job.world, all_reduce=job.all_reduce_sum if job.dist else None)
+                          world_size=job.world, reducer=reducer)
         if state.step == snapshot_step:
             snap["params"] = state.params.clone()          # 4 MB device copy
 
     for s in range(warmup):
         one_step(s)
     job.sync()
-    ops.profile_enable(not getattr(a, "no_kernel_events", False))
+    ops.profile_enable(not a.no_kernel_events)
     t0 = time.perf_counter()
     for s in range(warmup, warmup + steps):
         one_step(s)
@@ -252,7 +288,8 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None):
     deg = model.cfg.sh_deg
     out = {"elapsed": elapsed, "per_gpu": per_gpu, "deg": deg, "kernels": read_kernels(ops, deg),
            "stats": dict(zip(utils.Stats._fields, state.stats.cpu().tolist())), "args": args,
-           "model": model, "state": state, "dataset": dataset}
+           "model": model, "state": state, "dataset": dataset, "one_step": one_step,
+           "collectives_per_step": 2 if reducer.active else 0}
     if snapshot_step is not None:
         for s in range(state.step, snapshot_step):          # untimed: a short run did not get there
             one_step(s)
@@ -261,37 +298,82 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None):
     return out
 
 
-def run_strong512(job, a):
+def run_converge(job, a):
+    """The second half of BASELINE.json's metric: eval PSNR.  A fixed training budget from the fixed-seed initialisation
+    (`--converge-steps` steps of `--batch` rays per GPU, the headline's step), then render_image of held-out views of the
+    TEST split with deterministic sampling (nerf_sh/eval.py:57, nerf_sh/train.py:245-268, utils.py:331-381) and
+    compute_psnr (utils.py:384-393) against their ground truth."""
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    job.sync()
+    t0 = time.perf_counter()
+    tr = run_train(job, a.preset, a.converge_steps, 0)
+    t_train = tr["elapsed"]
+    test = datasets.Synthetic("test", tr["args"], job.device)
+    model, state = tr["model"], tr["state"]
+    comm = job.comm()
+    n_views = min(a.converge_views, test.size)
+    psnrs = []
+    job.sync()
+    t1 = time.perf_counter()
+    for i in range(n_views):
+        ex = test.get_image(i * (test.size // n_views))
+        rgb, _, _ = utils.render_image(lambda r: model.apply(state, r, False), ex["rays"], chunk=a.batch * job.world,
+                                       world_size=job.world, rank=job.rank, gather=comm.all_gather_cat)
+        psnrs.append(utils.compute_psnr(((rgb - ex["pixels"]) ** 2).mean().item()))
+    job.sync()
+    t_render = job.max_over_ranks(time.perf_counter() - t1)
+    return {"eval_psnr": sum(psnrs) / len(psnrs), "eval_psnr_per_view": psnrs, "views": n_views,
+            "view_size": [test.h, test.w], "train_steps": a.converge_steps, "rays_per_step": tr["per_gpu"] * job.world,
+            "train_s": t_train, "train_rays_per_s": tr["per_gpu"] * job.world * a.converge_steps / t_train,
+            "train_psnr_last_batch": tr["stats"]["psnr"], "render_s": t_render,
+            "render_rays_per_s": n_views * test.h * test.w / t_render, "wall_s": time.perf_counter() - t0,
+            "data": "synthetic analytic scene (three shaded spheres, white background): 100 train / 200 test poses, "
+                    "datasets.Synthetic; seed-fixed initialisation and batches",
+            "sampling": "train randomized (Philox), eval deterministic"}
+
+
+def run_strong(job, a):
     """The strong-scaling shape of BASELINE configs[2]: the reference's global batch of 4096 rays over 8 GPUs = 512
-    rays per GPU per step (train.py:117-118: one pmean per step).  Measured on this job's GPUs with 512 rays each and
-    the per-step collective issued through RCCL even with one rank (the gradient arena + stats, one all-reduce), so
-    the number is what one GPU of an 8-GPU strong-scaling run does before the wire time of that all-reduce."""
-    import torch.distributed as dist_mod
-    own_group = False
+    rays per GPU per step (train.py:117-118: pmean per step).  Measured on this job's GPUs with 512 rays each and
+    the per-step collectives issued through RCCL even with one rank (two buckets, dist.GradReducer), so the number is
+    what one GPU of an 8-GPU strong-scaling run does before the wire time of the exchange."""
+    own_group, err = False, None
     if job.dist is None:
         try:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29533 + os.getpid() % 2000))
-            dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=job.device)
-            job.dist, own_group = dist_mod, True
+            job.init_group()
+            own_group = True
         except Exception as e:                       # the record then says so instead of failing the bench
-            own_group = None
             err = repr(e)[:200]
-    k = max(40, a.steps)
-    t = run_train(job, a.preset, k, 5, per_gpu=512)
-    rec = {"value": 512 * job.world * k / t["elapsed"], "unit": "rays/s", "rays_per_gpu": 512, "steps": k,
-           "ms_per_step": 1e3 * t["elapsed"] / k, "collectives_per_step": 1 if job.dist else 0,
-           "frac": 512 * k / t["elapsed"] * FLOP_TRAIN_PER_RAY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12),
+    rays = a.strong_rays
+    k = max(40, a.steps) if job.cuda else a.steps
+    t = run_train(job, a.preset, k, 5 if job.cuda else 1, per_gpu=rays)
+    rec = {"value": rays * job.world * k / t["elapsed"], "unit": "rays/s", "rays_per_gpu": rays, "steps": k,
+           "ms_per_step": 1e3 * t["elapsed"] / k, "collectives_per_step": t["collectives_per_step"],
+           "frac": rays * k / t["elapsed"] * FLOP_TRAIN_PER_RAY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12),
            "kernels": [{"kernel": e["kernel"], "avg_ms": e["avg_ms"], "tflops": e.get("tflops")} for e in t["kernels"]],
            "note": "per-GPU work of the 8-GPU strong-scaling run of the reference's 4096-ray batch; 10k sparsity points "
                    "per GPU per step (train.py:78-80) are not counted as rays"}
     if own_group:
         job.sync()
-        dist_mod.destroy_process_group()
+        job.dist.destroy_process_group()
         job.dist = None
-    elif own_group is None:
+    elif err:
         rec["rccl_init_error"] = err
     return rec
+
+
+def run_coarse64(job, a):
+    """BASELINE configs[0] shape on the GPU ("1k rays x 64 samples", north_star's "800x800x64-sample batches"): the
+    coarse level only (num_fine_samples = 0; sparsity points ride with the coarse pass), 1024 and `--batch` rays."""
+    out = {}
+    for rays in sorted({min(1024, a.batch), a.batch}):
+        k = max(20, a.steps // 2) if job.cuda else a.steps
+        t = run_train(job, a.preset, k, 3 if job.cuda else 1, per_gpu=rays, num_fine_samples=0)
+        v = rays * job.world * k / t["elapsed"]
+        out[f"rays{rays}"] = {"value": v, "unit": "rays/s", "steps": k, "ms_per_step": 1e3 * t["elapsed"] / k,
+                              "frac": v / job.world * FLOP_TRAIN_PER_RAY_COARSE_ONLY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+    out["workload"] = "64 coarse samples per ray, no fine level (SURVEY 8d: 189.2 MFLOP per ray), 10k sparsity points"
+    return out
 
 
 def split_precision_twin(tr):
@@ -312,6 +394,8 @@ def run_render(job, tr, iters=20):
     model, state = tr["model"], tr["eval_state"]
     batch = next(tr["dataset"])
     rays = batch["rays"]
+    if not job.cuda:
+        iters = 2
     for _ in range(2):
         model.apply(state, rays, False)
     job.sync()
@@ -329,7 +413,7 @@ def run_render(job, tr, iters=20):
             "frac": rps / job.world * FLOP_RENDER_PER_RAY[tr["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
 
 
-def run_grid512(job, tr, stages_after_grid=True):
+def run_grid(job, tr, stages_after_grid=True):
     """BASELINE configs[4]: step 1 of octree.extraction at init_grid_depth 8 (octree/extraction.py:288-352):
     sigma of MLP_1 on the 512^3 grid (x-slabs sharded over the ranks + all-gather), the weight mask over the 100
     training views (cameras sharded + max-all-reduce) and the tree build."""
@@ -338,10 +422,10 @@ def run_grid512(job, tr, stages_after_grid=True):
     from plenoctree_amd.octree.svox import N3Tree
     model, state, dataset = tr["model"], tr["eval_state"], tr["dataset"]
     comm = job.comm()
-    reso, center, radius = 512, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5]
+    reso, center, radius = job.a.grid_reso, [0.0, 0.0, 0.0], [1.5, 1.5, 1.5]
     if model.cfg.mlp_precision == 0:
         state.repack(need_bwd=False)
-    extraction.grid_sigma(model, state, 64, center, radius, comm)       # warm-up (small grid)
+    extraction.grid_sigma(model, state, min(64, reso), center, radius, comm)       # warm-up (small grid)
     job.sync()
     t0 = time.perf_counter()
     sig = extraction.grid_sigma(model, state, reso, center, radius, comm)
@@ -351,15 +435,15 @@ def run_grid512(job, tr, stages_after_grid=True):
         del sig
         tflops = reso ** 3 * FLOP_SIGMA_PER_POINT / t_grid / 1e12
         return {"points": reso ** 3, "grid_ms": 1e3 * t_grid, "equivalent_f32_tflops": tflops}
-    tree = N3Tree(N=2, data_dim=1 + 3 * (tr["deg"] + 1) ** 2, init_refine=0, depth_limit=8, radius=radius,
-                  center=center, data_format=f"SH{(tr['deg'] + 1) ** 2}", map_location=job.device)
+    tree = N3Tree(N=2, data_dim=1 + 3 * (tr["deg"] + 1) ** 2, init_refine=0, depth_limit=int(math.log2(reso)) - 1,
+                  radius=radius, center=center, data_format=f"SH{(tr['deg'] + 1) ** 2}", map_location=job.device)
     t0 = time.perf_counter()
     weights = extraction.calculate_grid_weights(dataset, sig, reso, tree.invradius, tree.offset, 1e-4, comm)
     job.sync()
     t_weight = job.max_over_ranks(time.perf_counter() - t0)
     # an untrained network has no surfaces: threshold sigma at its 97th percentile, i.e. a mask of ~4 M voxels as a
     # trained scene leaves (the build time depends on how many voxels are set, not on which)
-    thr = float(torch.quantile(sig[::4099].float(), 0.97))
+    thr = float(torch.quantile(sig[::4099 if reso >= 64 else 1].float(), 0.97))
     job.sync()
     t0 = time.perf_counter()
     mask = oops.threshold_mask(sig, thr)
@@ -377,44 +461,59 @@ def run_grid512(job, tr, stages_after_grid=True):
             "tree_nodes": int(tree.n_internal), "sharding": f"x-slabs over {job.world} GPU(s) + all-gather"}
 
 
-def main():
-    a = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(a))
+        raise SystemExit(self_launch(a, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if a.backend == "nccl" and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU; the HIP path has no CPU fallback")
     job = Job(a)
     rank = job.rank
 
-    from plenoctree_amd import build
-    if rank == 0:
-        build.build(verbose=False)
-    if job.dist:
-        job.dist.barrier()
+    if job.cuda:
+        from plenoctree_amd import build
+        if rank == 0:
+            build.build(verbose=False)
+        if job.dist:
+            job.dist.barrier()
 
-    tr = run_train(job, a.preset, a.steps, a.warmup, snapshot_step=None if a.no_extras else EVAL_STEP)
+    want = [] if a.no_extras else [e for e in a.extras.split(",") if e]
+    unknown = [e for e in want if e not in ALL_EXTRAS]
+    if unknown:
+        raise SystemExit(f"bench.py --extras: unknown record(s) {unknown}")
+    need_snapshot = any(e in want for e in ("render_fwd", "grid512", "bf16x3"))
+    tr = run_train(job, a.preset, a.steps, a.warmup, snapshot_step=a.eval_step if need_snapshot else None)
     extras = {}
-    if not a.no_extras:
-        extras["strong512"] = run_strong512(job, a)
+    if "strong512" in want:
+        extras["strong512"] = run_strong(job, a)
+    if "render_fwd" in want:
         extras["render_fwd"] = run_render(job, tr)
-        extras["grid512"] = run_grid512(job, tr)
+    if "grid512" in want:
+        extras["grid512"] = run_grid(job, tr)
+    if "bf16x3" in want:
         # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
         twin = split_precision_twin(tr)
-        r3, g3 = run_render(job, twin), run_grid512(job, twin, stages_after_grid=False)
+        r3, g3 = run_render(job, twin), run_grid(job, twin, stages_after_grid=False)
         extras["opt_in_bf16x3_inference"] = {
             "note": "PxoCfg.mlp_precision = bf16x3: forward-only, |dPSNR| vs the f64 oracle <= 1e-4 dB (tests/test_gpu_x3.py); "
                     "training and the headline stay float32",
             "render_fwd_rays_per_s": r3["value"], "render_fwd_ms_per_call": r3["ms_per_call"],
             "grid512_ms": g3["grid_ms"], "grid512_equivalent_f32_tflops": g3["equivalent_f32_tflops"]}
         twin = None
-        other = "tt" if a.preset == "blender" else "blender"
-        tr["state"] = tr["eval_state"] = tr["dataset"] = None   # release the headline workspace before the second preset
+    head = {k: tr[k] for k in ("per_gpu", "deg", "kernels", "elapsed", "stats", "args", "collectives_per_step")}
+    tr = None                                  # release the headline workspace (19 GB) before the other presets
+    if job.cuda:
         torch.cuda.empty_cache()
-        k2 = max(10, a.steps // 4)
-        t2 = run_train(job, other, k2, 3)
+    if "coarse64" in want:
+        extras["coarse64"] = run_coarse64(job, a)
+    if "tt_sh25" in want:
+        other = "tt" if a.preset == "blender" else "blender"
+        k2 = max(10, a.steps // 4) if job.cuda else a.steps
+        t2 = run_train(job, other, k2, 3 if job.cuda else 1)
         v2 = t2["per_gpu"] * world * k2 / t2["elapsed"]
         extras["tt_sh25" if other == "tt" else "blender_sh16"] = {
             "value": v2, "unit": "rays/s", "steps": k2, "ms_per_step": 1e3 * t2["elapsed"] / k2,
@@ -423,19 +522,28 @@ def main():
             "workload": "nerf_sh/config/tt.yaml: SH25, near 0, far 4, sparsity_length 0.2, sparsity_radius 5"
                         if other == "tt" else "nerf_sh/config/blender.yaml"}
         t2 = None
+        if job.cuda:
+            torch.cuda.empty_cache()
+    if "converge" in want:
+        extras["converge"] = run_converge(job, a)
 
+    # the CPU baseline is timed on rank 0's host cores only, whatever the world size (the other ranks wait at the barrier)
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a, head["args"], a.cpu_rays, a.cpu_steps, job.device)
     if rank == 0:
-        per_gpu, deg, kernels = tr["per_gpu"], tr["deg"], tr["kernels"]
-        elapsed = tr["elapsed"]
+        per_gpu, deg, kernels = head["per_gpu"], head["deg"], head["kernels"]
+        elapsed = head["elapsed"]
         value = per_gpu * world * a.steps / elapsed
         dom = kernels[0] if kernels else None            # mlp_fwd_kernel: largest single launch of the step
         roofline = None
         if dom:
+            traffic, source = hbm_traffic("mlp_fwd_kernel")
             roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                         "flop_per_launch": dom["rows_per_launch"] * FLOP_FWD_PER_ROW[deg],
-                        "traffic": hbm_traffic("mlp_fwd_kernel")}
+                        "traffic": traffic, "traffic_source": source}
         out = {
             "metric": "training rays/sec (800x800, 64+128 samples)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -446,23 +554,29 @@ def main():
                                    "800x800 synthetic views, sparsity 10k pts, Adam",
                        "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
                        "parallelism": f"dp{world}"},
-            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": 1 if job.dist else 0,
+            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": head["collectives_per_step"],
             "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
-            "final_stats": tr["stats"],
+            "final_stats": head["stats"],
             "roofline": roofline, "kernels": kernels,
         }
+        if "converge" in extras:
+            out["eval_psnr"] = extras["converge"]["eval_psnr"]      # the metric's second half, next to `value`
         out.update(extras)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tr["args"], a.cpu_rays, a.cpu_steps, job.device)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if not job.cuda:
+            out["dry_run"] = "gloo ranks on CPU with the test harness's stand-ins: control flow only, numbers meaningless"
         print(json.dumps(out), flush=True)
         # RCCL keeps its version banner in the C stdio buffer until the process exits: whatever libraries still flush to
         # fd 1 after this point goes to stderr, so that the JSON line above stays the only line on stdout
         sys.stdout.flush()
-        os.dup2(2, 1)
+        if job.cuda:
+            os.dup2(2, 1)
     if job.dist:
         job.dist.barrier()
         job.dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -236,6 +236,29 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
                       const float* t_rand, const float* u, const float* sp_points, uint64_t seed,
                       float* grads, float* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* The same, for data-parallel training with the gradient exchange split in two buckets.  The kernels are sequenced
+ * coarse level first -- forward, losses, reverse through MLP_0 -- and only then the fine level (the reference's single
+ * jax.value_and_grad, nerf_sh/train.py:116, leaves the order to XLA; no gradient of the fine level reaches MLP_0 because
+ * the fine sample positions are stop_gradient'ed, nerf_sh/nerf/model_utils.py:286).  `grads0_ready` (a hipEvent_t, e.g.
+ * from pxo_event_create; may be NULL) is recorded on `stream` at the point where grads[0 .. n_mlp) -- MLP_0's
+ * sub-arena, weight decay included -- is final: a second stream that waits for it can run lax.pmean of that half
+ * (train.py:117) under the fine level, while grads[n_mlp .. 2 n_mlp) and stats follow at the end of the call.
+ * pxo_train_fwd_bwd is this function with grads0_ready = NULL. */
+int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const float* packed_fwd0,
+                               const float* packed_bwd0, const float* packed_fwd1,
+                               const float* packed_bwd1, const float* origins, const float* directions,
+                               const float* viewdirs, const float* pixels, int64_t B, int randomized,
+                               const float* t_rand, const float* u, const float* sp_points, uint64_t seed,
+                               float* grads, float* stats, void* ws, size_t ws_bytes, void* grads0_ready,
+                               void* stream);
+
+/* Plain event handles for the call above (hipEventDisableTiming), so that a host runtime whose own event objects are
+ * lazily created or private (torch.cuda.Event) can still order its collective stream behind the bucket:
+ * pxo_stream_wait_event(side_stream, ev) = "side_stream continues once the last record of ev has completed". */
+int pxo_event_create(void** event);
+int pxo_event_destroy(void* event);
+int pxo_stream_wait_event(void* stream, void* event);
+
 /* NerfModel.eval_points_raw (octree/nerf/models.py:211-252; call sites
  * octree/extraction.py:271,316,373).  raw_rgb may be NULL (step1 keeps sigma only). */
 int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* points, int64_t N,

@@ -115,6 +115,15 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
  * order); process-wide. */
 int pxo_octree_set_lanes_per_ray(int forward, int backward);
 
+/* The other two launch-time choices between kernels that compute the SAME result (A/B sessions, the bit-equality test of
+ * the two weight-mask marchers); process-wide, validated, no environment variables are read anywhere in the library.
+ *   PXO_TUNE_GW_MARCHER      -1 chosen on the device by the occupied fraction of the grid (default), 0 per-sample, 1 slab-staged
+ *   PXO_TUNE_BWD_CACHE_ROWS  rows of the backward renderer's per-wave write-combining cache: 16 (default), 0 (direct
+ *                            scatter), 4, 8, 32, 64 */
+#define PXO_TUNE_GW_MARCHER 0
+#define PXO_TUNE_BWD_CACHE_ROWS 1
+int pxo_octree_set_tuning(int knob, int value);
+
 /* Forward.  Rays come either from `cam` (cam != NULL: B must be width*height, ray r = pixel
  * (r % width, r / width), out [H,W,3]) or from explicit arrays origins/dirs/viewdirs [B,3] in world
  * space with unit dirs (cam == NULL).  out_rgb [B,3]. */

@@ -106,6 +106,11 @@ SIGNATURES = {
     "pxo_train_workspace_bytes": (c_int, [CFG, c_int64, POINTER(c_size_t)]),
     "pxo_train_fwd_bwd": (c_int, [CFG, P, P, P, P, P, P, P, P, P, c_int64, c_int, P, P, P, c_uint64, P, P,
                                   P, c_size_t, P]),
+    "pxo_train_fwd_bwd_bucketed": (c_int, [CFG, P, P, P, P, P, P, P, P, P, c_int64, c_int, P, P, P, c_uint64, P, P,
+                                           P, c_size_t, P, P]),
+    "pxo_event_create": (c_int, [POINTER(c_void_p)]),
+    "pxo_event_destroy": (c_int, [P]),
+    "pxo_stream_wait_event": (c_int, [P, P]),
     "pxo_eval_points": (c_int, [CFG, P, P, c_int64, P, P, P]),
     "pxo_profile_enable": (c_int, [c_int]),
     "pxo_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_int64)]),
@@ -123,6 +128,7 @@ SIGNATURES = {
     "pxo_grid_weight_render": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
                                        F3, F3, P, P, c_size_t, P]),
     "pxo_octree_set_lanes_per_ray": (c_int, [c_int, c_int]),
+    "pxo_octree_set_tuning": (c_int, [c_int, c_int]),
     "pxo_octree_render_fwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,

@@ -1407,6 +1407,8 @@ int pxo_grid_weight_workspace_bytes(int reso, size_t* bytes) {
   return PXO_OK;
 }
 
+static int g_gw_marcher = -1;   // -1: chosen on the device; 0 / 1: forced (pxo_octree_set_tuning)
+
 int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
                            int width, int height, const PxoRenderOpts* opts, const float offset[3],
                            const float invradius[3], float* grid_weight, void* ws, size_t ws_bytes, void* stream) {
@@ -1442,11 +1444,10 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)(brick_blocks < 8192 ? brick_blocks : 8192)), dim3(256), 0, s, sigma_grid,
                      reso, sigma_b, opts->sigma_thresh, occupied);
   const bool pow2 = (reso & (reso - 1)) == 0 && reso <= 1024;
-  // PXO_GW_SLAB = 1 | 0 forces the slab-staged / the per-sample marcher (A/B runs, the equality test); unset: chosen on the
-  // device by the fraction of voxels above sigma_thresh (GwSelect).  Slab window width measured at 4 / 5 / 6 bricks:
+  // pxo_octree_set_tuning(PXO_TUNE_GW_MARCHER, 1 | 0) forces the slab-staged / the per-sample marcher (A/B runs, the
+  // equality test); default -1: chosen on the device by the fraction of voxels above sigma_thresh (GwSelect).  Slab window width measured at 4 / 5 / 6 bricks:
   // 1.245 / 1.257 / 1.262 ms per camera (the staging is not what bounds the marcher); 6 keeps nearly every sample of a tile inside.
-  const char* gw_env = getenv("PXO_GW_SLAB");
-  const int force = gw_env ? (atoi(gw_env) != 0 ? 1 : 0) : -1;
+  const int force = g_gw_marcher;
   if (pow2)
     hipLaunchKernelGGL(grid_weight_pow2_kernel, dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso, c2w_all, n_cams, fx,
                        fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b), GwSelect{occupied, n, force});
@@ -1468,30 +1469,20 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
 // with compile-time K (KF) then takes SH16 to 1.61 ms, SH25 to 2.35 ms, SH9 to 1.75 ms.
 // Backward at "4 lanes" is octree_render_bwd4_kernel (4-lane march, 16-lane cooperative scatter): 10.47 ms reusing the
 // forward image / 11.20 ms without, against 10.86 / 11.90 ms for the 16-lane kernel (SH25: 14.46 / 15.49 against 14.87 / 16.02).
-// So: 4 lanes both ways.  PXO_OCT_ROW = 4 | 8 | 16 forces one value for A/B runs.
+// So: 4 lanes both ways.  pxo_octree_set_lanes_per_ray forces a value for A/B runs and the per-instantiation tests.
 static int g_row_override[2] = {0, 0};   // [forward, backward]; 0 = the measured default
 static int render_row(bool backward, int data_dim) {
-  static const int forced = [] {
-    const char* e = getenv("PXO_OCT_ROW");
-    const int v = e ? atoi(e) : 0;
-    return (v == 4 || v == 8 || v == 16) ? v : 0;
-  }();
   if (g_row_override[backward ? 1 : 0]) return g_row_override[backward ? 1 : 0];
-  if (forced) return forced;
   (void)data_dim;
   return 4;
 }
 
 // Rows of the backward kernel's per-wave write-combining cache.  Measured (800x800, SH16, reusing the forward image):
 // 9.7 ms direct scatter, 5.0 / 4.8 / 4.4 / 4.3 ms with 4 / 8 / 16 / 32 rows; two-march form 10.3 -> 6.3 / 6.1 / 5.6 / 6.3 (32 rows
-// cost occupancy: 35 KB of LDS per workgroup).  PXO_OCT_WC = 0 | 4 | 8 | 16 | 32 | 64 forces one value for A/B runs.
-static int bwd_wc_slots() {
-  static const int v = [] {
-    const char* e = getenv("PXO_OCT_WC");
-    return e ? atoi(e) : 16;
-  }();
-  return v;
-}
+// cost occupancy: 35 KB of LDS per workgroup).  pxo_octree_set_tuning(PXO_TUNE_BWD_CACHE_ROWS, 0 | 4 | 8 | 16 | 32 | 64)
+// selects another instantiation for A/B runs (0 = direct scatter); anything else is rejected there.
+static int g_bwd_wc_rows = 16;
+static int bwd_wc_slots() { return g_bwd_wc_rows; }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
                        const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const char* who, bool backward,
@@ -1533,6 +1524,23 @@ int pxo_octree_set_lanes_per_ray(int forward, int backward) {
   g_row_override[0] = forward;
   g_row_override[1] = backward;
   return PXO_OK;
+}
+
+int pxo_octree_set_tuning(int knob, int value) {
+  switch (knob) {
+    case PXO_TUNE_GW_MARCHER:
+      PXO_REQUIRE(value >= -1 && value <= 1, "pxo_octree_set_tuning: marcher must be -1 (chosen on the device), 0 (per-sample) or 1 (slab-staged)");
+      g_gw_marcher = value;
+      return PXO_OK;
+    case PXO_TUNE_BWD_CACHE_ROWS:
+      PXO_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64,
+                  "pxo_octree_set_tuning: write-combining rows must be 0, 4, 8, 16, 32 or 64 (got %d)", value);
+      g_bwd_wc_rows = value;
+      return PXO_OK;
+    default:
+      set_error("pxo_octree_set_tuning: unknown knob %d", knob);
+      return PXO_ERR_ARG;
+  }
 }
 
 int pxo_octree_render_fwd(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,16 +77,22 @@ KernelTimer::~KernelTimer() {
 }
 
 // Side stream of pxo_train_fwd_bwd: the parameter norm (weight_l2) depends on the parameters only and is issued beside
-// the forward pass, between a fork event on the caller's stream and a join back into it.  Created on first use for
-// the current device (one process drives one GPU), never destroyed.
+// the forward pass, between a fork event on the caller's stream and a join back into it.  One set per device, created
+// under a lock on first use for the device that is current at the call, never destroyed.
 struct SideStreams {
   static constexpr int kN = 1;
   hipStream_t s[kN] = {nullptr};
   hipEvent_t fork[1] = {}, join[1][kN] = {};
   bool ok = false;
 };
-static SideStreams& side_streams() {
-  static SideStreams ss;
+static SideStreams* side_streams() {
+  constexpr int kMaxDevices = 64;
+  static SideStreams table[kMaxDevices];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStreams& ss = table[dev];
   if (!ss.ok) {
     bool good = true;
     for (int i = 0; i < SideStreams::kN; ++i) good = good && hipStreamCreateWithFlags(&ss.s[i], hipStreamNonBlocking) == hipSuccess;
@@ -94,9 +101,17 @@ static SideStreams& side_streams() {
       for (int i = 0; i < SideStreams::kN; ++i)
         good = good && hipEventCreateWithFlags(&ss.join[f][i], hipEventDisableTiming) == hipSuccess;
     }
-    ss.ok = good;
+    if (!good) {          // nothing half-made is kept: the next call starts from scratch
+      for (int i = 0; i < SideStreams::kN; ++i) if (ss.s[i]) { (void)hipStreamDestroy(ss.s[i]); ss.s[i] = nullptr; }
+      for (int f = 0; f < 1; ++f) {
+        if (ss.fork[f]) { (void)hipEventDestroy(ss.fork[f]); ss.fork[f] = nullptr; }
+        for (int i = 0; i < SideStreams::kN; ++i) if (ss.join[f][i]) { (void)hipEventDestroy(ss.join[f][i]); ss.join[f][i] = nullptr; }
+      }
+      return nullptr;
+    }
+    ss.ok = true;
   }
-  return ss;
+  return &ss;
 }
 // fork point `f`: side stream i may start once everything issued so far on `main` is done
 static bool fork_to(SideStreams& ss, int f, hipStream_t main, int i) {
@@ -106,6 +121,16 @@ static bool fork_to(SideStreams& ss, int f, hipStream_t main, int i) {
 static bool join_from(SideStreams& ss, int f, hipStream_t main, int i) {
   return hipEventRecord(ss.join[f][i], ss.s[i]) == hipSuccess && hipStreamWaitEvent(main, ss.join[f][i], 0) == hipSuccess;
 }
+// Once a fork succeeded the caller's stream must re-join the side stream on EVERY exit path: a failed launch further
+// down would otherwise return with the side kernel unordered against whatever the caller does next with `params`
+// (and an enclosing stream capture would be left forked).
+struct JoinGuard {
+  SideStreams& ss;
+  hipStream_t main;
+  bool armed = true;
+  ~JoinGuard() { if (armed) (void)join_from(ss, 0, main, 0); }
+  bool join() { armed = false; return join_from(ss, 0, main, 0); }
+};
 
 // bump allocator over the caller's workspace; with base == nullptr it only measures
 struct Carver {
@@ -199,17 +224,17 @@ static void carve_train(const PxoCfg* cfg, int64_t B, void* ws, bool train, Trai
     if (_rc != PXO_OK) return _rc; \
   } while (0)
 
-// forward of NerfModel.__call__ into the pass buffers.  pixels != nullptr selects the training form: compositing,
-// the pixel loss and its reverse in one kernel per pass (d_raw_* and ray_sse are written, the rgb/disp/acc outputs are
-// not), with the sparsity rows of the last pass served by the same launch.
-static int run_forward(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* pk1, const float* o,
-                       const float* d, const float* v, int64_t B, int randomized, const float* t_rand,
-                       const float* u, const float* sp_points, uint64_t seed, const float* pixels, float* rgb_c,
-                       float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f, hipStream_t s) {
+// NerfModel.__call__ (nerf_sh/nerf/models.py:216-348) in three pieces, so that the training sequence can put the reverse of
+// the coarse level between the levels.  pixels != nullptr selects the training form: compositing, the pixel loss and its
+// reverse in one kernel per pass (d_raw_* and ray_sse are written, the rgb/disp/acc outputs are not), with the sparsity
+// rows of the last pass served by the same launch.
+struct Draws { const float* t_rand; const float* u; };
+
+// every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
+static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomized, const float* t_rand, const float* u,
+                         const float* sp_points, uint64_t seed, hipStream_t s, Draws& out) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
-  const bool train = pixels != nullptr;
   PassBuffers& last = Nf > 0 ? t.f : t.c;
-  // every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
   UniformJob jobs[3];
   int nj = 0;
   if (randomized && !t_rand) { jobs[nj++] = UniformJob{0, B * Nc, 0.f, 1.f, t.t_rand}; t_rand = t.t_rand; }
@@ -226,28 +251,35 @@ static int run_forward(const PxoCfg* cfg, TrainWs& t, const float* pk0, const fl
       jobs[nj++] = UniformJob{2, t.n_sp * 3, -cfg->sparsity_radius, cfg->sparsity_radius, dst};
     }
   }
-  PXO_TRY(launch_uniform_jobs(seed, jobs, nj, s));
-  // coarse pass
-  PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, t_rand, t.c.z, t.c.pts, s));
+  out.t_rand = t_rand; out.u = u;
+  return launch_uniform_jobs(seed, jobs, nj, s);
+}
+
+static int forward_coarse(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* o, const float* d, const float* v,
+                          int64_t B, const Draws& dr, const float* pixels, float* rgb_c, float* disp_c, float* acc_c,
+                          hipStream_t s) {
+  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, dr.t_rand, t.c.z, t.c.pts, s));
   PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s));
-  if (train)
-    PXO_TRY(launch_shade_composite_train(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, pixels, B, Nc, nullptr,
-                                         Nf > 0 ? t.c.weights : nullptr, t.c.ray_sse, t.c.d_raw_rgb, t.c.d_raw_sigma,
-                                         Nf > 0 ? 0 : t.n_sp, t.sp_exp, s));
-  else
-    PXO_TRY(launch_shade_composite_fwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, B, Nc, rgb_c, disp_c, acc_c,
-                                       t.c.weights, s));
-  if (Nf > 0) {
-    PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, u, t.f.z, t.f.pts, s));
-    PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
-    if (train)
-      PXO_TRY(launch_shade_composite_train(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, pixels, B, Nc + Nf, nullptr,
-                                           nullptr, t.f.ray_sse, t.f.d_raw_rgb, t.f.d_raw_sigma, t.n_sp, t.sp_exp, s));
-    else
-      PXO_TRY(launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f,
-                                         acc_f, t.f.weights, s));
-  }
-  return PXO_OK;
+  if (pixels)
+    return launch_shade_composite_train(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, pixels, B, Nc, nullptr,
+                                        Nf > 0 ? t.c.weights : nullptr, t.c.ray_sse, t.c.d_raw_rgb, t.c.d_raw_sigma,
+                                        Nf > 0 ? 0 : t.n_sp, t.sp_exp, s);
+  return launch_shade_composite_fwd(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, B, Nc, rgb_c, disp_c, acc_c,
+                                    t.c.weights, s);
+}
+
+static int forward_fine(const PxoCfg* cfg, TrainWs& t, const float* pk1, const float* o, const float* d, const float* v,
+                        int64_t B, const Draws& dr, const float* pixels, float* rgb_f, float* disp_f, float* acc_f,
+                        hipStream_t s) {
+  const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
+  PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, dr.u, t.f.z, t.f.pts, s));
+  PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
+  if (pixels)
+    return launch_shade_composite_train(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, pixels, B, Nc + Nf, nullptr,
+                                        nullptr, t.f.ray_sse, t.f.d_raw_rgb, t.f.d_raw_sigma, t.n_sp, t.sp_exp, s);
+  return launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f, acc_f,
+                                    t.f.weights, s);
 }
 
 }  // namespace pxo
@@ -455,8 +487,13 @@ int pxo_render_fwd(const PxoCfg* cfg, const float* packed_fwd0, const float* pac
     set_error("pxo_render_fwd: workspace %zu < %zu", ws_bytes, t.total);
     return PXO_ERR_WORKSPACE;
   }
-  return run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
-                     nullptr, seed, nullptr, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  Draws dr;
+  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, nullptr, seed, s, dr));
+  PXO_TRY(forward_coarse(cfg, t, packed_fwd0, origins, directions, viewdirs, B, dr, nullptr, rgb_c, disp_c, acc_c, s));
+  if (cfg->num_fine_samples > 0)
+    PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, nullptr, rgb_f, disp_f, acc_f, s));
+  return PXO_OK;
 }
 
 int pxo_train_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes) {
@@ -468,11 +505,11 @@ int pxo_train_workspace_bytes(const PxoCfg* cfg, int64_t B, size_t* bytes) {
   return PXO_OK;
 }
 
-int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packed_fwd0, const float* packed_bwd0,
-                      const float* packed_fwd1, const float* packed_bwd1, const float* origins,
-                      const float* directions, const float* viewdirs, const float* pixels, int64_t B, int randomized,
-                      const float* t_rand, const float* u, const float* sp_points, uint64_t seed, float* grads,
-                      float* stats, void* ws, size_t ws_bytes, void* stream) {
+int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const float* packed_fwd0, const float* packed_bwd0,
+                               const float* packed_fwd1, const float* packed_bwd1, const float* origins,
+                               const float* directions, const float* viewdirs, const float* pixels, int64_t B,
+                               int randomized, const float* t_rand, const float* u, const float* sp_points, uint64_t seed,
+                               float* grads, float* stats, void* ws, size_t ws_bytes, void* grads0_ready, void* stream) {
   PXO_TRY(validate_cfg(cfg));
   PXO_REQUIRE(B >= 1 && params && packed_fwd0 && packed_bwd0 && origins && directions && viewdirs && pixels && grads &&
                   stats && ws,
@@ -492,31 +529,69 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   }
   const int deg = cfg->sh_deg;
   const int64_t n_mlp = mlp_param_count(deg);
-  SideStreams& ss = side_streams();
-  if (!ss.ok) { set_error("pxo_train_fwd_bwd: could not create the side streams"); return PXO_ERR_HIP; }
+  const float wd_coef = 2.f * cfg->weight_decay_mult / (float)(2 * n_mlp);   // d/dp of weight_decay_mult * sum(p^2)/n (train.py:101-114)
+  SideStreams* ssp = side_streams();
+  if (!ssp) { set_error("pxo_train_fwd_bwd: could not create the side streams"); return PXO_ERR_HIP; }
+  SideStreams& ss = *ssp;
   // weight_l2 = sum(p^2) / n (train.py:101-108) depends on the parameters only: its partial sums run beside the forward pass
   float* const sumsq_partial = t.scalars;
   if (!fork_to(ss, 0, s, 0)) { set_error("pxo_train_fwd_bwd: stream fork failed"); return PXO_ERR_HIP; }
+  JoinGuard guard{ss, s};
   PXO_TRY(launch_sumsq_partials(params, 2 * n_mlp, sumsq_partial, ss.s[0]));
-  // forward, losses (train.py:77-98) and the reverse of the compositing
-  PXO_TRY(run_forward(cfg, t, packed_fwd0, packed_fwd1, origins, directions, viewdirs, B, randomized, t_rand, u,
-                      sp_points, seed, pixels, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
-  // reverse through the MLPs
+  Draws dr;
+  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, sp_points, seed, s, dr));
+  // coarse level: forward, losses (train.py:77-98), reverse of the compositing, reverse through MLP_0.  Nothing of the fine
+  // level feeds MLP_0's gradient (the fine sample positions carry no gradient, model_utils.py:286), so it is complete here
+  // -- a quarter into the step -- and its all-reduce can ride under the fine level.
+  PXO_TRY(forward_coarse(cfg, t, packed_fwd0, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
   PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, s));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
                                  grads, t.wgrad_ws, t.wgrad_bytes, s));
+  if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads, params, n_mlp, wd_coef, s));
+  if (grads0_ready && hipEventRecord((hipEvent_t)grads0_ready, s) != hipSuccess) {
+    set_error("pxo_train_fwd_bwd: hipEventRecord(grads0_ready) failed");
+    return PXO_ERR_HIP;
+  }
   if (Nf > 0) {
+    PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
     PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, s));
     PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
                                    grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, s));
   } else {
     PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
   }
-  if (cfg->weight_decay_mult != 0.f)   // + weight_decay_mult * weight_l2 (train.py:101-114)
-    PXO_TRY(launch_axpy(grads, params, 2 * n_mlp, 2.f * cfg->weight_decay_mult / (float)(2 * n_mlp), s));
-  if (!join_from(ss, 0, s, 0)) { set_error("pxo_train_fwd_bwd: stream join failed"); return PXO_ERR_HIP; }
+  if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads + n_mlp, params + n_mlp, n_mlp, wd_coef, s));
+  if (!guard.join()) { set_error("pxo_train_fwd_bwd: stream join failed"); return PXO_ERR_HIP; }
   PXO_TRY(launch_finalize_stats(Nf > 0 ? t.f.ray_sse : nullptr, t.c.ray_sse, t.n_sp > 0 ? t.sp_exp : nullptr, sumsq_partial,
                                 B, t.n_sp, cfg->sparsity_weight, 2 * n_mlp, stats, s));
+  return PXO_OK;
+}
+
+int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packed_fwd0, const float* packed_bwd0,
+                      const float* packed_fwd1, const float* packed_bwd1, const float* origins,
+                      const float* directions, const float* viewdirs, const float* pixels, int64_t B, int randomized,
+                      const float* t_rand, const float* u, const float* sp_points, uint64_t seed, float* grads,
+                      float* stats, void* ws, size_t ws_bytes, void* stream) {
+  return pxo_train_fwd_bwd_bucketed(cfg, params, packed_fwd0, packed_bwd0, packed_fwd1, packed_bwd1, origins, directions,
+                                    viewdirs, pixels, B, randomized, t_rand, u, sp_points, seed, grads, stats, ws, ws_bytes,
+                                    nullptr, stream);
+}
+
+// plain handles for the bucketed form: the caller's runtime (torch) creates its events lazily and keeps them private
+int pxo_event_create(void** event) {
+  PXO_REQUIRE(event != nullptr, "pxo_event_create: NULL pointer");
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreateWithFlags failed"); return PXO_ERR_HIP; }
+  *event = (void*)e;
+  return PXO_OK;
+}
+int pxo_event_destroy(void* event) {
+  if (event && hipEventDestroy((hipEvent_t)event) != hipSuccess) { set_error("hipEventDestroy failed"); return PXO_ERR_HIP; }
+  return PXO_OK;
+}
+int pxo_stream_wait_event(void* stream, void* event) {
+  PXO_REQUIRE(event != nullptr, "pxo_stream_wait_event: NULL event");
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return PXO_ERR_HIP; }
   return PXO_OK;
 }
 

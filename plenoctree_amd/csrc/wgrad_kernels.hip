@@ -374,9 +374,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // (rays/s at 4096 / 1024 / 512 rays per step, 256 CUs): 256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k /
   // 144.3 k / 127.9 k (one launch per layer: 159.7 k / 139.9 k / 120.3 k) - long ranges lose on big passes (the two
   // column halves drift apart and the shared operand stops hitting L2), short ones pay 64 MB of slab traffic per layer.
-  static const int ranges_override = getenv("PXO_WGRAD_RANGES") ? atoi(getenv("PXO_WGRAD_RANGES")) : 0;   // A/B hook
   int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
-  if (ranges_override > 0 && ranges_override <= num_cus()) ranges = ranges_override;
   int64_t rpwb; int Pb;
   split_rows(M, ranges, &rpwb, &Pb);
   float* const slab_main = reinterpret_cast<float*>(ws);

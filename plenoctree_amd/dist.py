@@ -55,6 +55,62 @@ class Comm:
             torch.distributed.destroy_process_group()
 
 
+class GradReducer:
+    """lax.pmean(grad) + lax.pmean(stats) (nerf_sh/train.py:117-118) as TWO sum-all-reduces per step instead of one
+    after the backward pass: MLP_0's half of the gradient arena is final once the coarse level has been reversed -- a
+    quarter into the step (pxo_train_fwd_bwd_bucketed) -- and is reduced on a side stream under the fine level; MLP_1's
+    half with the 6 stats in its tail follows when the step's kernels are through.  The caller's stream waits for both
+    before Adam, so the reduced values -- and the bit-identical replicas -- are those of the single call.
+
+    On RCCL both collectives run on the process group's own stream in issue order (bucket 0, bucket 1); what the side
+    stream adds is the *dependency*: bucket 0 waits for the library's `grads0_ready` event only, not for the kernels
+    queued behind it.  With gloo (CPU tests) the two calls are simply made in that order.  `all_reduce` replaces the
+    collective (tests count the calls through it)."""
+
+    def __init__(self, comm, device=None, all_reduce=None, force=False):
+        self.comm = comm
+        self.active = comm.is_dist or force or all_reduce is not None
+        self.all_reduce = all_reduce
+        self.on_gpu = device is not None and device.type == "cuda"
+        self.event = self.side = self.bucket0_done = None
+        self.record_timing = False            # tests: make `bucket0_done` a timing event
+        if self.active and self.on_gpu:
+            from . import ops
+            self.event = ops.Event()
+            self.side = torch.cuda.Stream(device=device)
+
+    def ready_event(self):
+        """What pxo_train_fwd_bwd_bucketed records when bucket 0 is final (None: no overlap, e.g. on the CPU)."""
+        return self.event
+
+    def _reduce(self, t, async_op):
+        if self.all_reduce is not None:
+            self.all_reduce(t)
+            return None
+        return torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, async_op=async_op)
+
+    def reduce(self, bucket0, bucket1):
+        """Sum both buckets over the ranks; on return the current stream is ordered after both collectives."""
+        if not self.active:
+            return
+        if self.side is None:
+            self._reduce(bucket0, False)
+            self._reduce(bucket1, False)
+            return
+        with torch.cuda.stream(self.side):
+            self.event.wait(self.side)              # ... and nothing else of this step
+            w0 = self._reduce(bucket0, True)
+            if w0 is not None:
+                w0.wait()                           # side stream ordered after the collective
+            done0 = torch.cuda.Event(enable_timing=self.record_timing)
+            done0.record(self.side)
+        w1 = self._reduce(bucket1, True)            # ordered after everything queued on the current stream
+        if w1 is not None:
+            w1.wait()
+        torch.cuda.current_stream().wait_event(done0)
+        self.bucket0_done = done0                   # tests time it against the end of the step's kernels
+
+
 def init_from_env(backend=None, device=None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

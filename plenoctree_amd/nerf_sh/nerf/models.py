@@ -29,6 +29,9 @@ class TrainState:
         self.grads = self.reduce_buf[:params.numel()]
         self.stats = self.reduce_buf[params.numel():params.numel() + 6]
         self.n_mlp = params.numel() // 2
+        # the two exchange buckets (dist.GradReducer): MLP_0's gradient | MLP_1's gradient + stats
+        self.bucket0 = self.reduce_buf[:self.n_mlp]
+        self.bucket1 = self.reduce_buf[self.n_mlp:]
         self.packed = [None, None]
         self._ws = None
         self.repack()
@@ -122,24 +125,25 @@ def get_model_state(args, device, restore=True):
 
 
 def train_step(model, state, batch, lr, randomized=True, t_rand=None, u=None, sp_points=None, seed=0,
-               world_size=1, all_reduce=None):
+               world_size=1, reducer=None):
     """One optimisation step (nerf_sh/train.py:51-121) on this rank's shard of the batch.
 
-    loss_fn + value_and_grad run in pxo_train_fwd_bwd; `all_reduce` (one RCCL sum over ranks of the
-    flat gradient arena with the 6 stats in its tail) implements lax.pmean (train.py:117-118); Adam
-    (train.py:119) and the re-pack of the weight images follow.  Returns the device tensor
-    stats[6] = (loss, psnr, loss_c, loss_sp, psnr_c, weight_l2); its values are only read by
-    the host when logging."""
+    loss_fn + value_and_grad run in pxo_train_fwd_bwd_bucketed; `reducer` (dist.GradReducer: two RCCL sums over the ranks,
+    MLP_0's half of the gradient arena under the fine level, MLP_1's half with the 6 stats in its tail at the end)
+    implements lax.pmean (train.py:117-118); Adam (train.py:119) and the re-pack of the weight images follow.  Returns
+    the device tensor stats[6] = (loss, psnr, loss_c, loss_sp, psnr_c, weight_l2); its values are only read by the
+    host when logging."""
     cfg = model.cfg
     rays = batch["rays"]
     B = rays.origins.shape[0]
     ws = state.workspace(ops.train_workspace_bytes(cfg, B))
+    ev = reducer.ready_event() if reducer is not None else None
     ops.train_fwd_bwd(cfg, state.params, state.packed, rays.origins, rays.directions, rays.viewdirs, batch["pixels"],
                       state.grads, state.stats, ws, randomized=randomized, t_rand=t_rand, u=u, sp_points=sp_points,
-                      seed=seed)
+                      seed=seed, grads0_ready=ev)
     scale = 1.0
-    if all_reduce is not None:
-        all_reduce(state.reduce_buf)        # gradients + stats, one RCCL call (a no-op Comm at world size 1)
+    if reducer is not None:
+        reducer.reduce(state.bucket0, state.bucket1)
     if world_size > 1:
         state.stats.mul_(1.0 / world_size)
         scale = 1.0 / world_size

@@ -39,6 +39,7 @@ def main(argv=None):
         print(f"* {2 * state.n_mlp} parameters, resuming at step {init_step}, {comm.world} GPU(s), "
               f"{per_rank} rays/GPU", flush=True)
 
+    reducer = dist.GradReducer(comm, device)
     t_loop_start = time.time()
     stats_trace = []
     reset_timer = True
@@ -51,7 +52,7 @@ def main(argv=None):
         lr = utils.learning_rate_decay(step, args.lr_init, args.lr_final, args.max_steps, args.lr_delay_steps,
                                        args.lr_delay_mult)
         models.train_step(model, state, batch, lr, randomized=args.randomized, seed=(step << 8) | comm.rank,
-                          world_size=comm.world, all_reduce=comm.all_reduce_sum)
+                          world_size=comm.world, reducer=reducer)
         if step % args.print_every == 0:                            # train.py:208-236
             torch.cuda.synchronize()
             s = utils.Stats(*state.stats.cpu().tolist())

@@ -152,6 +152,14 @@ def set_lanes_per_ray(forward=0, backward=0):
     check(_lib.load().pxo_octree_set_lanes_per_ray(int(forward), int(backward)), "pxo_octree_set_lanes_per_ray")
 
 
+TUNE_GW_MARCHER, TUNE_BWD_CACHE_ROWS = 0, 1
+
+
+def set_tuning(knob, value):
+    """pxo_octree_set_tuning: choose between kernels that compute the same result (A/B sessions, equality tests)."""
+    check(_lib.load().pxo_octree_set_tuning(int(knob), int(value)), "pxo_octree_set_tuning")
+
+
 def octree_render_persp(tree, c2w, width, height, fx, opts, fy=None):
     """[H,W,3] image of a pinhole camera (VolumeRenderer.render_persp)."""
     _require_gpu()

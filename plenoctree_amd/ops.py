@@ -269,16 +269,41 @@ def render_fwd(cfg, packed_fwd0, packed_fwd1, origins, directions, viewdirs, ran
 
 
 def train_fwd_bwd(cfg, params, packed, origins, directions, viewdirs, pixels, grads, stats, ws, randomized=True,
-                  t_rand=None, u=None, sp_points=None, seed=0):
-    """loss_fn + value_and_grad on this device's shard; fills grads (2-MLP arena) and stats[6]."""
+                  t_rand=None, u=None, sp_points=None, seed=0, grads0_ready=None):
+    """loss_fn + value_and_grad on this device's shard; fills grads (2-MLP arena) and stats[6].
+    grads0_ready: an `Event` recorded on the current stream once MLP_0's half of `grads` is final (the coarse level is
+    reversed before the fine level starts), or None."""
     _require_gpu()
     lib = _lib.load()
     (f0, b0), (f1, b1) = packed
     B = origins.shape[0]
-    check(lib.pxo_train_fwd_bwd(ctypes.byref(cfg), _f(params), _f(f0), _f(b0), _f(f1), _f(b1), _f(origins),
-                                _f(directions), _f(viewdirs), _f(pixels), B, int(randomized), _f(t_rand), _f(u),
-                                _f(sp_points), seed, _f(grads), _f(stats), _p(ws), ws.numel(), _stream()),
-          "pxo_train_fwd_bwd")
+    check(lib.pxo_train_fwd_bwd_bucketed(ctypes.byref(cfg), _f(params), _f(f0), _f(b0), _f(f1), _f(b1), _f(origins),
+                                         _f(directions), _f(viewdirs), _f(pixels), B, int(randomized), _f(t_rand), _f(u),
+                                         _f(sp_points), seed, _f(grads), _f(stats), _p(ws), ws.numel(),
+                                         grads0_ready.handle if grads0_ready is not None else None, _stream()),
+          "pxo_train_fwd_bwd_bucketed")
+
+
+class Event:
+    """hipEvent_t owned through the C ABI (pxo_event_create): recorded by pxo_train_fwd_bwd_bucketed, waited for by
+    `wait(stream)`."""
+
+    def __init__(self):
+        _require_gpu()
+        h = ctypes.c_void_p(None)
+        check(_lib.load().pxo_event_create(ctypes.byref(h)), "pxo_event_create")
+        self.handle = h
+
+    def wait(self, stream):
+        """`stream` (a torch.cuda.Stream) continues once the last record of this event has completed."""
+        check(_lib.load().pxo_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), self.handle), "pxo_stream_wait_event")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().pxo_event_destroy(self.handle)
+        except Exception:
+            pass
 
 
 def eval_points(cfg, packed_fwd, points, want_rgb=True):

@@ -1,0 +1,137 @@
+#!/bin/bash
+# The ONE GPU-box session script (replaces the per-round gpu_*.sh files).  Runs the stages named in $STAGES, in order:
+#
+#   tests      pytest -m gpu (PYTEST_ARGS / PYTEST_K narrow it), then __graft_entry__ smoke
+#   bench      python bench.py $BENCH_ARGS                     -> gpurun_out/bench.json
+#   prof       rocprofv3 --kernel-trace --stats of the headline bench (+ gap analysis)   -> gpurun_out/prof
+#   pmc        four rocprofv3 --pmc passes of the same command (own runs, no trace domains) -> gpurun_out/pmc{1..4}
+#   timeline   per-step kernel timelines at the batch sizes in $BATCHES (default 512)      -> gpurun_out/timeline_b*.txt
+#   ab_trees   bench.py alternately in the trees $TREES ("_ab_base ." default), ROUNDS x per batch -> gpurun_out/ab_trees.txt
+#   ab_env     run-time / variant-library A/B of ONE tree: VARIANTS="name|ENV=v ENV2=v|bench args;..." -> gpurun_out/$AB_TAG.txt
+#   octree     tests/test_gpu_octree.py + scripts/octree_bench.py $OBENCH_ARGS               -> gpurun_out/octree_bench.json
+#   oprof      rocprofv3 stats + FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py   -> gpurun_out/oprof, opmc{1,2}
+#   pipeline   train -> eval -> extraction -> optimization -> evaluation through the drop-in CLIs -> gpurun_out/converge.log
+#   power      clocks / power sampled while a long bench runs                               -> gpurun_out/smi.log
+#
+#   gpurun --timeout 1500 -- 'STAGES="tests bench prof" bash scripts/gpu_session.sh'
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R=$PWD
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+HEAD_ARGS="--no-cpu-baseline --no-extras"
+nproc > gpurun_out/device.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/device.txt
+
+brief() {   # one line per bench JSON: rays/s, ms/step, kernels
+  python - "$1" "${2:-}" "${3:-}" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(sys.argv[2], "B", sys.argv[3] or d["config"]["rays_per_gpu"], round(d["value"]), "rays/s", round(d["ms_per_step"], 4), "ms/step",
+          [(k["kernel"][:14], round(k["avg_ms"], 4), round(k.get("tflops", 0), 1)) for k in d["kernels"]])
+except Exception as e:
+    print(sys.argv[2], "B", sys.argv[3], "no result", e)
+PY
+}
+medians() {
+  python - "$1" <<'PY' | tee -a "$1"
+import collections, statistics, sys
+runs = collections.defaultdict(list)
+for ln in open(sys.argv[1]):
+    p = ln.split()
+    if len(p) > 6 and p[1] == "B" and p[4] == "rays/s":
+        runs[(p[0], p[2])].append(float(p[5]))
+for (t, b), v in sorted(runs.items(), key=lambda kv: (int(kv[0][1]), kv[0][0])):
+    print(f"median  {t:14s} B {b:>5s}: {statistics.median(v):.4f} ms/step = {int(b) / statistics.median(v) * 1e3:,.0f} rays/s  (n={len(v)}, min {min(v):.4f})")
+PY
+}
+
+for stage in ${STAGES:-tests bench}; do
+  echo "=== stage $stage"
+  case $stage in
+  tests)
+    rm -f gpurun_out/fullsize_parity.jsonl
+    timeout ${TEST_TIMEOUT:-1800} python -m pytest tests -m gpu --durations=15 -q --tb=short -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+    echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+    tail -${TEST_TAIL:-40} gpurun_out/pytest_gpu.log
+    cat gpurun_out/fullsize_parity.jsonl gpurun_out/trained_psnr.json gpurun_out/trained_psnr_twin512.json 2>/dev/null
+    timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
+    tail -3 gpurun_out/smoke.log ;;
+  bench)
+    timeout ${BENCH_TIMEOUT:-1200} python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err
+    echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
+  prof)
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 $HEAD_ARGS ${PROF_ARGS:-} > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
+    echo "rocprof exit $?"; cd "$R"
+    f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f"
+    f=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/gap_analysis.py "$f" | tee gpurun_out/gaps.txt
+    find gpurun_out -name "*.csv" -size +30M -delete ;;
+  pmc)
+    cd /tmp; i=0
+    for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 $HEAD_ARGS > /dev/null 2> "$R/gpurun_out/pmc$i.err"
+      echo "pmc pass $i exit $?"
+    done
+    cd "$R"; find gpurun_out -name "*.csv" -size +30M -delete ;;
+  timeline)
+    for B in ${BATCHES:-512}; do
+      timeout 300 python bench.py --batch $B --steps 40 --warmup 5 $HEAD_ARGS ${TL_ARGS:-} > gpurun_out/bench_b$B.json 2> gpurun_out/bench_b$B.err
+      echo "bench B=$B exit $?"; brief gpurun_out/bench_b$B.json timeline $B
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/trace_b$B" -o t -- python "$R/bench.py" --batch $B --steps 12 --warmup 3 $HEAD_ARGS ${TL_ARGS:-} > /dev/null 2> "$R/gpurun_out/trace_b$B.err"
+      echo "rocprof B=$B exit $?"; cd "$R"
+      f=$(find gpurun_out/trace_b$B -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python scripts/step_timeline.py "$f" 4 > gpurun_out/timeline_b$B.txt && head -${TL_HEAD:-50} gpurun_out/timeline_b$B.txt
+      find gpurun_out/trace_b$B -name "*.csv" -size +20M -delete
+    done ;;
+  ab_trees)
+    : > gpurun_out/ab_trees.txt
+    for B in ${BATCHES:-512}; do for r in $(seq 1 ${ROUNDS:-3}); do for t in ${TREES:-"_ab_base ."}; do
+      ( cd "$R/$t" && timeout 300 python bench.py --batch $B --steps ${AB_STEPS:-60} --warmup 5 $HEAD_ARGS ${AB_ARGS:-} 2> /dev/null ) > gpurun_out/ab_run.json
+      brief gpurun_out/ab_run.json "$t" $B | tee -a gpurun_out/ab_trees.txt
+    done; done; done
+    medians gpurun_out/ab_trees.txt ;;
+  ab_env)
+    OUT=gpurun_out/${AB_TAG:-ab_env}.txt; : > $OUT
+    IFS=';' read -ra VARS <<< "${VARIANTS:-base||}"
+    for B in ${BATCHES:-512}; do for r in $(seq 1 ${ROUNDS:-3}); do for v in "${VARS[@]}"; do
+      IFS='|' read -r name envs args <<< "$v"
+      ( [ -n "$envs" ] && export $envs; timeout 300 python bench.py --batch $B --steps ${AB_STEPS:-60} --warmup 5 $HEAD_ARGS $args 2> gpurun_out/ab_run.err ) > gpurun_out/ab_run.json
+      brief gpurun_out/ab_run.json "$name" $B | tee -a $OUT
+    done; done; done
+    medians $OUT ;;
+  octree)
+    timeout ${TEST_TIMEOUT:-600} python -m pytest tests/test_gpu_octree.py -m gpu --durations=8 -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_octree.log 2>&1
+    echo "pytest exit $?" >> gpurun_out/pytest_octree.log; tail -12 gpurun_out/pytest_octree.log
+    timeout 300 python scripts/octree_bench.py ${OBENCH_ARGS:-} > gpurun_out/octree_bench.json 2> gpurun_out/octree_bench.err
+    echo "octree_bench exit $?"; cat gpurun_out/octree_bench.json; tail -5 gpurun_out/octree_bench.err ;;
+  oprof)
+    cd /tmp
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/oprof" -o obench -- python "$R/scripts/octree_bench.py" --cams 4 > "$R/gpurun_out/oprof_bench.json" 2> "$R/gpurun_out/oprof.err"
+    echo "octree rocprof exit $?"; i=0
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/gpurun_out/opmc$i" -o pmc -- python "$R/scripts/octree_bench.py" --cams 2 > /dev/null 2> "$R/gpurun_out/opmc$i.err"
+      echo "octree pmc pass $i exit $?"
+    done
+    cd "$R"; find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
+    python scripts/summarize_octree_prof.py gpurun_out gpurun_out tmp ;;
+  pipeline)
+    mkdir -p /tmp/pxo_conv
+    printf 'dataset: synthetic\nfactor: 0\nnum_coarse_samples: 64\nnum_fine_samples: 128\nuse_viewdirs: false\nwhite_bkgd: true\nbatch_size: 4096\nsh_deg: 3\nrandomized: true\nmax_steps: %s\nprint_every: 250\nsave_every: %s\nrender_every: 1000\nchunk: 8192\n' ${PIPE_STEPS:-3000} ${PIPE_STEPS:-3000} > /tmp/pxo_conv/cfg.yaml
+    C="--train_dir /tmp/pxo_conv --config /tmp/pxo_conv/cfg.yaml"
+    timeout 400 python -m plenoctree_amd.nerf_sh.train $C > gpurun_out/converge.log 2>&1; echo "train exit $?"
+    timeout 200 python -m plenoctree_amd.nerf_sh.eval $C --approx_eval_skip 50 --save_output false >> gpurun_out/converge.log 2>&1; echo "eval exit $?"
+    timeout 300 python -m plenoctree_amd.octree.extraction $C --init_grid_depth 8 --output /tmp/pxo_conv/tree.npz >> gpurun_out/converge.log 2>&1; echo "extraction exit $?"
+    timeout 300 python -m plenoctree_amd.octree.optimization $C --input /tmp/pxo_conv/tree.npz --output /tmp/pxo_conv/tree_opt.npz --num_epochs ${OPT_EPOCHS:-4} --val_interval 2 >> gpurun_out/converge.log 2>&1; echo "optimization exit $?"
+    timeout 200 python -m plenoctree_amd.octree.evaluation $C --input /tmp/pxo_conv/tree_opt.npz >> gpurun_out/converge.log 2>&1; echo "evaluation exit $?"
+    grep -v amdgpu.ids gpurun_out/converge.log | tail -45 ;;
+  power)
+    ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Power|mclk|Temperature \(Sensor (edge|junction)" | tr '\n' ' ' ; echo; sleep 0.5; done ) > gpurun_out/smi.log &
+    timeout 120 python bench.py --steps 400 --warmup 3 $HEAD_ARGS > gpurun_out/bench_long.json 2> gpurun_out/bench_long.err
+    wait; brief gpurun_out/bench_long.json power; sed -n '1p;8p;16p;24p;32p' gpurun_out/smi.log | cut -c1-400 ;;
+  *) echo "unknown stage $stage" ;;
+  esac
+done

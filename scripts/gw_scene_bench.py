@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Weight-mask stage of bench.py's grid512 record (sigma grid of the fixed-seed NeRF after 105 steps, 100 training views
 in one pxo_grid_weight_render call) under several settings of the kernel's run-time switches.
-usage: gw_scene_bench.py "PXO_GW_SLAB=0" "PXO_GW_DRAIN=64" "" ...   (one timing per argument; "" = defaults)"""
+usage: gw_scene_bench.py "marcher=0" "marcher=1" "" ...   (one timing per argument; "" = chosen on the device;
+marcher -> octree_ops.set_tuning(TUNE_GW_MARCHER, v))"""
 import json
 import os
 import sys
@@ -16,10 +17,10 @@ import bench  # noqa: E402
 
 def main():
     settings = sys.argv[1:] or [""]
-    sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    a = bench.parse()
+    a = bench.parse(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     job = bench.Job(a)
-    tr = bench.run_train(job, a.preset, a.steps, a.warmup, snapshot_step=bench.EVAL_STEP)
+    tr = bench.run_train(job, a.preset, a.steps, a.warmup, snapshot_step=a.eval_step)
+    from plenoctree_amd import octree_ops as oops
     from plenoctree_amd.octree import extraction
     from plenoctree_amd.octree.svox import N3Tree
     model, state, dataset = tr["model"], tr["eval_state"], tr["dataset"]
@@ -32,20 +33,18 @@ def main():
     out = [{"sigma_positive_fraction": float((sig > 0).float().mean()), "sigma_gt_1": float((sig > 1).float().mean())}]
     for rep in range(2):
         for st in settings:
-            keys = []
             for kv in st.split(","):
                 if kv:
                     k, v = kv.split("=")
-                    os.environ[k] = v
-                    keys.append(k)
+                    assert k == "marcher", k
+                    oops.set_tuning(oops.TUNE_GW_MARCHER, int(v))
             job.sync()
             t0 = time.perf_counter()
             w = extraction.calculate_grid_weights(dataset, sig, reso, tree.invradius, tree.offset, 1e-4, comm)
             job.sync()
             dt = time.perf_counter() - t0
             out.append({"setting": st, "rep": rep, "ms": 1e3 * dt, "voxels": int((w >= 1e-3).sum()), "sum": float(w.double().sum())})
-            for k in keys:
-                del os.environ[k]
+            oops.set_tuning(oops.TUNE_GW_MARCHER, -1)
             del w
     for o in out:
         print(json.dumps(o), flush=True)

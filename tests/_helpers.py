@@ -220,3 +220,38 @@ def philox_randint(seed, stream_id, count, n):
             if 2 * q + i < count:
                 out[2 * q + i] = ((w[2 * i] << 32) | w[2 * i + 1]) % n
     return out
+
+
+# ---- the mid-scale trained-PSNR twin (tests/golden/make_trained_twin.py <-> test_trained_psnr_twin_512_rays) ------------
+TWIN_RAYS, TWIN_STEPS = 512, 300
+
+
+def _twin_args():
+    from plenoctree_amd.nerf_sh.nerf import utils
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
+    utils.update_flags(args); args.factor = 8             # 100 x 100 views of the analytic scene
+    return args
+
+
+def twin_steps(B, steps, cfg):
+    """(step, host batch, t_rand, u, sp_points, lr) of the twin run: batches from the CPU feeder (np.random.RandomState, as
+    the reference's sampler), randoms from per-step torch generators, the reference's log-linear lr schedule
+    5e-4 -> 5e-6 annealed over the horizon (nerf_sh/nerf/utils.py:483-515).  Seeds only: both legs regenerate it."""
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    ds = datasets.get_dataset("train", _twin_args(), torch.device("cpu"), batch_size=B)
+    for step in range(steps):
+        batch = next(ds)
+        g = torch.Generator().manual_seed(5000 + step)
+        t_rand = torch.rand(B, cfg.num_coarse_samples, generator=g); u = torch.rand(B, cfg.num_fine_samples, generator=g)
+        sp = (torch.rand(cfg.sparsity_npoints, 3, generator=g) * 2 - 1) * cfg.sparsity_radius
+        yield step, batch, t_rand, u, sp, utils.learning_rate_decay(step, 5e-4, 5e-6, steps)
+
+
+def twin_heldout():
+    """Held-out rays / pixels: every 4th pixel of three views of the TEST split."""
+    from plenoctree_amd.nerf_sh.nerf import datasets
+    test_ds = datasets.get_dataset("test", _twin_args(), torch.device("cpu"))
+    views = [test_ds.get_image(i) for i in (0, 67, 133)]
+    rays = O.Rays(*[torch.cat([t["rays"][k].reshape(-1, 3)[::4] for t in views]).contiguous() for k in range(3)])
+    px = torch.cat([t["pixels"].reshape(-1, 3)[::4] for t in views])
+    return rays, px

@@ -1,0 +1,53 @@
+"""Oracle leg of the mid-scale trained-PSNR twin (tests/test_gpu_parity.py::test_trained_psnr_twin_512_rays).
+
+north_star: "PSNR within 0.1 dB" is stated for 4096-ray batches; the in-test twin (64 rays x 400 steps) is toy-sized
+because the oracle runs at ~270 rays/s.  This script runs the ORACLE (oracle/nerf_oracle.py, float32, the pinned CPU
+restatement of nerf_sh/train.py:51-121) for 300 Adam steps of 512 rays x (64+128) samples + 10,000 sparsity points -- the
+per-GPU step of the reference's 4096-ray batch on 8 devices -- and stores the parameters it ends with.  The GPU test
+replays the same batches and injected randoms (tests/_helpers.py:twin_steps, seeds only) through the HIP path and
+compares held-out PSNRs.  ~15 minutes on 8 cores:
+    python tests/golden/make_trained_twin.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import nerf_oracle as O  # noqa: E402
+import _helpers as H  # noqa: E402
+
+
+def main():
+    from _cpu_feeder import feeder_for
+    from plenoctree_amd.nerf_sh.nerf import datasets
+    datasets.Dataset.feeder_factory = staticmethod(feeder_for)
+    B, steps = H.TWIN_RAYS, H.TWIN_STEPS
+    cfg = O.Cfg()
+    torch.set_num_threads(os.cpu_count() or 1)
+    flat0 = O.flatten_params(O.init_params(cfg, seed=20200823))
+    p, m, v = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
+    t0 = time.time()
+    for step, batch, t_rand, u, sp, lr in H.twin_steps(B, steps, cfg):
+        p, m, v, st, _ = O.train_step(p, m, v, step, O.Rays(*batch["rays"]), batch["pixels"], cfg, t_rand, u, sp, lr)
+        if step % 10 == 0:
+            print(f"step {step}: loss {float(st['loss']):.5f} psnr {float(st['psnr']):.3f}  ({time.time() - t0:.0f} s)", flush=True)
+    rays, px = H.twin_heldout()
+    with torch.no_grad():
+        trained = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
+        init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]
+    out = dict(params=p.numpy(), rays_per_step=B, steps=steps, psnr_init=H._psnr(init, px), psnr_trained=H._psnr(trained, px),
+               torch_version=torch.__version__, threads=torch.get_num_threads())
+    print({k: v for k, v in out.items() if k != "params"})
+    np.savez_compressed(os.path.join(HERE, f"trained_twin_{B}x{steps}.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,8 @@ def _patch_ops(cfg):
         return mlp_params, mlp_params
 
     def train_fwd_bwd(pcfg, params, packed, o, d, v, px, grads, stats, ws, randomized=True, t_rand=None, u=None,
-                      sp_points=None, seed=0):
+                      sp_points=None, seed=0, grads0_ready=None):
+        assert grads0_ready is None          # no device events on the CPU: the reducer then makes its two calls in order
         _, st, g = O.loss_and_grad(params, O.Rays(o, d, v), px, cfg, t_rand, u, sp_points)
         grads.copy_(g)
         stats.copy_(torch.stack([st[k] for k in ("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")]))
@@ -107,19 +108,23 @@ def _worker(rank, world, port, outdir):
     calls = []
 
     def counted_all_reduce(t):
-        calls.append(t.numel())
+        calls.append((t.data_ptr(), t.numel()))
         comm.all_reduce_sum(t)
 
+    reducer = dist.GradReducer(comm, all_reduce=counted_all_reduce)
     for step in range(STEPS):
         t_rand, u, sp = rnd[step]
         batch = {"rays": utils.Rays(*[r[sl].contiguous() for r in rays]), "pixels": px[sl].contiguous()}
         lr = utils.learning_rate_decay(step, 5e-4, 5e-6, 100)
         models.train_step(model, state, batch, lr, t_rand=t_rand[sl].contiguous(), u=u[sl].contiguous(),
-                          sp_points=sp, world_size=comm.world, all_reduce=counted_all_reduce)
+                          sp_points=sp, world_size=comm.world, reducer=reducer)
     assert state.step == STEPS
-    # lax.pmean(grad) + lax.pmean(stats) (train.py:117-118) = exactly one collective per step: the gradient arena
-    # with the 6 stats in its tail
-    assert calls == [flat.numel() + 8] * STEPS, calls
+    # lax.pmean(grad) + lax.pmean(stats) (train.py:117-118) = exactly two collectives per step, in this order: MLP_0's half
+    # of the gradient arena (final after the coarse level: it rides under the fine level on the GPU), then MLP_1's half
+    # with the 6 stats in its tail; together they cover the arena exactly once
+    n_mlp = flat.numel() // 2
+    base = state.reduce_buf.data_ptr()
+    assert calls == [(base, n_mlp), (base + 4 * n_mlp, n_mlp + 8)] * STEPS, calls
     # render_image: padded chunks, per-rank slices, all-gather (nerf_sh/nerf/utils.py:357-371)
     H, W = 5, 7                                   # 35 rays: odd, chunk 16 -> padding on every chunk
     g = torch.Generator().manual_seed(3)

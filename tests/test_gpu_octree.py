@@ -148,20 +148,17 @@ def test_grid_weight_render_matches_oracle(reso, W, H, fx):
     assert (want > 0).sum() > 50
     close("grid weights", got, torch.from_numpy(want), rtol=1e-5, atol=1e-6)
     # the slab-staged kernel and the per-sample kernel take the same samples with the same arithmetic: bit-equal (the default
-    # call above picked one of them on the device by the fraction of voxels above sigma_thresh; PXO_GW_SLAB forces either)
-    import os
-    old = os.environ.get("PXO_GW_SLAB")
+    # call above picked one of them on the device by the fraction of voxels above sigma_thresh; the tuning knob forces either)
     forced = {}
     try:
         for mode in ("0", "1"):
-            os.environ["PXO_GW_SLAB"] = mode
+            oops.set_tuning(oops.TUNE_GW_MARCHER, int(mode))
             forced[mode] = oops.grid_weight_render(torch.from_numpy(sigma).to(dev), reso, torch.from_numpy(cams).to(dev), fx, fx,
                                                    W, H, oops.render_opts(1e-3), t.offset, t.invradius)
     finally:
-        if old is None:
-            del os.environ["PXO_GW_SLAB"]
-        else:
-            os.environ["PXO_GW_SLAB"] = old
+        oops.set_tuning(oops.TUNE_GW_MARCHER, -1)
+    with pytest.raises(Exception):
+        oops.set_tuning(oops.TUNE_BWD_CACHE_ROWS, 12)            # not an instantiation: rejected, not silently remapped
     assert torch.equal(forced["0"], forced["1"]) and torch.equal(forced["0"], got)
     # accumulating camera by camera == one call (torch.max over cameras, octree/extraction.py:206-212)
     acc = None

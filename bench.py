@@ -249,7 +249,7 @@ def read_kernels(ops, deg):
     return kernels
 
 
-def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, **flag_over):
+def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, events=True, **flag_over):
     """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats.
     snapshot_step: a copy of the parameters after exactly that many steps from the fixed-seed initialisation is kept
     (taken inside the run if it gets that far, by untimed extra steps otherwise), so that the records evaluated on
@@ -277,7 +277,10 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, **fl
     for s in range(warmup):
         one_step(s)
     job.sync()
-    ops.profile_enable(not a.no_kernel_events)
+    # Inside the timed region only the dominant kernel (mlp_fwd, the `roofline` leg) is bracketed by HIP events: an event
+    # record is a barrier packet between two kernels that would otherwise dispatch back to back (~5 us each; with all
+    # four tags on, 16 brackets = 0.13 ms of a 3.7 ms step at 512 rays -- profiles/r04a_events_ab.txt).
+    ops.profile_enable(tags=[] if (a.no_kernel_events or not events) else [ops.PROF_MLP_FWD])
     t0 = time.perf_counter()
     for s in range(warmup, warmup + steps):
         one_step(s)
@@ -286,8 +289,22 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, **fl
     ops.profile_enable(False)
     elapsed = job.max_over_ranks(elapsed)
     deg = model.cfg.sh_deg
-    out = {"elapsed": elapsed, "per_gpu": per_gpu, "deg": deg, "kernels": read_kernels(ops, deg),
-           "stats": dict(zip(utils.Stats._fields, state.stats.cpu().tolist())), "args": args,
+    stats = dict(zip(utils.Stats._fields, state.stats.cpu().tolist()))
+    dom = read_kernels(ops, deg)
+    kernels = dom
+    if events and not a.no_kernel_events and job.cuda:
+        # the table of the other kernels: a few more steps, untimed, every tag bracketed (mlp_fwd's row stays the timed one)
+        extra = min(10, max(steps, 1))
+        ops.profile_enable(True)
+        for s in range(warmup + steps, warmup + steps + extra):
+            one_step(s)
+        job.sync()
+        ops.profile_enable(False)
+        kernels = dom + [k for k in read_kernels(ops, deg) if k["kernel"] != "mlp_fwd_kernel"]
+        for k in kernels[len(dom):]:
+            k["from"] = f"{extra} untimed steps after the timed region"
+    out = {"elapsed": elapsed, "per_gpu": per_gpu, "deg": deg, "kernels": kernels,
+           "stats": stats, "args": args,
            "model": model, "state": state, "dataset": dataset, "one_step": one_step,
            "collectives_per_step": 2 if reducer.active else 0}
     if snapshot_step is not None:
@@ -306,7 +323,7 @@ def run_converge(job, a):
     from plenoctree_amd.nerf_sh.nerf import datasets, utils
     job.sync()
     t0 = time.perf_counter()
-    tr = run_train(job, a.preset, a.converge_steps, 0)
+    tr = run_train(job, a.preset, a.converge_steps, 0, events=False)
     t_train = tr["elapsed"]
     test = datasets.Synthetic("test", tr["args"], job.device)
     model, state = tr["model"], tr["state"]

@@ -273,13 +273,18 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing of the dominant kernels on the stream they are launched on (bench.py's
  * roofline leg; the reference only has wall-clock rays/sec, nerf_sh/train.py:222-226).
- * Tags: 0 mlp_fwd, 1 mlp_bwd_data, 2 wgrad 256x256 GEMM, 3 other wgrad GEMMs. */
+ * Tags: 0 mlp_fwd, 1 mlp_bwd_data, 2 wgrad 256x256 GEMM, 3 other wgrad GEMMs.
+ * pxo_profile_enable(mask): bit t set = launches tagged t are bracketed by two event records; 0 = off,
+ * PXO_PROF_ALL = every tag.  An event record costs the stream ~5 us (a barrier packet between two kernels that
+ * would otherwise dispatch back to back: measured, profiles/r04*), so a timed region that must stay representative
+ * enables only the tag it needs. */
 #define PXO_PROF_MLP_FWD 0
 #define PXO_PROF_MLP_BWD_DATA 1
 #define PXO_PROF_WGRAD_MAIN 2
 #define PXO_PROF_WGRAD_OTHER 3
 #define PXO_PROF_NUM_TAGS 4
-int pxo_profile_enable(int on);
+#define PXO_PROF_ALL ((1 << PXO_PROF_NUM_TAGS) - 1)
+int pxo_profile_enable(int tag_mask);
 /* Synchronises the recorded events and returns launches / total ms / total rows processed
  * for `tag` since the last read; resets the tag. */
 int pxo_profile_read(int tag, int64_t* launches, double* total_ms, int64_t* total_rows);

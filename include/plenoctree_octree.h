@@ -140,6 +140,23 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
                           const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
                           const float* grad_out, float* grad_data, void* stream);
 
+/* ---- work counters of the marchers (roofline pass: scripts/octree_bench.py states each kernel's algorithmic bytes from
+ *      these; nothing on the product path calls them) ----
+ * One thread per ray repeats the renderer's / the weight mask's march -- same ray set-up, leaf lookup, step rule and early
+ * stop, hence the same sample sequence -- and counts:
+ *   counts[0] rays that enter the volume        counts[2] samples with sigma > sigma_thresh (one leaf row read / one
+ *   counts[1] samples (one sigma read each)               weight update each)
+ *   counts[3] child-pointer loads of the leaf lookups (tree marcher only)
+ * counts: 4 device uint64, ACCUMULATED (zero them first).  leaf_seen [n_internal*8] / voxel_seen [reso^3] (uint8, may be
+ * NULL): set to 1 where a sample above the threshold fell, so that the distinct rows a launch must fetch from HBM at
+ * least once can be counted. */
+int pxo_octree_count_work(const PxoTree* tree, const PxoCamera* cam, const PxoRenderOpts* opts,
+                          unsigned long long* counts, uint8_t* leaf_seen, void* stream);
+int pxo_grid_weight_count_work(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
+                               int width, int height, const PxoRenderOpts* opts, const float offset[3],
+                               const float invradius[3], unsigned long long* counts, uint8_t* voxel_seen,
+                               void* stream);
+
 /* mse = mean((clamp(im,0,1) - gt)^2) and its gradient w.r.t. im  (octree/optimization.py:217-219);
  * n = number of floats.  sse_out: device scalar receiving sum of squares (mse = sse/n); grad may be NULL. */
 int pxo_image_mse(const float* im, const float* gt, int64_t n, float* grad, float* sse_out, void* stream);

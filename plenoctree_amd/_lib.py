@@ -133,6 +133,9 @@ SIGNATURES = {
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P, P, P]),
+    "pxo_octree_count_work": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), POINTER(PxoRenderOpts), P, P, P]),
+    "pxo_grid_weight_count_work": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
+                                           F3, F3, P, P, P]),
     "pxo_image_mse": (c_int, [P, P, c_int64, P, P, P]),
     "pxo_sgd_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_int, P]),
 }

@@ -234,6 +234,14 @@ struct WImage {
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t voff;       // lane * 16
 };
+// HARDWARE ASSUMPTION shared by every raw-buffer access in this file and in wgrad_kernels.hip: a gfx9 raw buffer
+// (stride 0, no swizzle; word 3 = 0x00020000) is range-checked on the SUM voffset + soffset + immediate offset against
+// num_records (bytes): a load past the end returns 0, a store past the end is dropped.  Ragged tiles rely on it --
+// num_records is set to the tile's valid bytes and the per-row part of the address travels in soffset / the immediate
+// (the compiler may move a constant between the two; both are inside the checked sum) -- so rows >= M of the last tile
+// are neither read from nor written into memory owned by another tile or layer.  Kept honest by the ragged-M parity tests
+// (tests/test_gpu_parity.py: test_mlp_fwd_saved_tensors M = 657 / 300, test_mlp_backward M = 424 / 200, which compare
+// acts, dz and every weight gradient with the oracle) -- a toolchain or architecture that checks differently fails them.
 __device__ __forceinline__ WImage make_wimage(const float* image, int64_t floats, int lane) {
   return WImage{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)(floats * 4), 0x00020000),
                 (uint32_t)lane * 16u};

@@ -700,6 +700,7 @@ struct RenderArgs {
 struct Marcher {
   uint32_t pX, pY, pZ;
   int last_depth;
+  int loads;                                   // child-pointer loads of the last find() (read by the counting kernel only)
   bool first;
   int* stack;                                  // LDS, kMaxD + 2 entries of this row
 
@@ -725,10 +726,12 @@ struct Marcher {
     pX = X; pY = Y; pZ = Z;
     int node = stack[depth];
     int cell;
+    loads = 0;
     while (true) {
       const int bit = kBits - 1 - depth;
       cell = (int)(((X >> bit) & 1u) << 2 | ((Y >> bit) & 1u) << 1 | ((Z >> bit) & 1u));
       const int skip = child[(int64_t)node * 8 + cell];
+      ++loads;
       if (skip == 0 || depth >= kMaxD) break;          // depth bound: a malformed file cannot spin the descent
       node += skip;
       ++depth;
@@ -1223,6 +1226,120 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
 }
 
 // ------------------------------------------------------------------------------------------
+// work counters (roofline pass, scripts/octree_bench.py): the marchers' own ray set-up, leaf lookup, step rule and
+// early stop -- same arithmetic, so the same sample sequence -- counting instead of shading.  One thread per ray.
+//   counts[0] rays that enter the volume      counts[2] samples above sigma_thresh (one full row / one weight update each)
+//   counts[1] samples (one sigma read each)   counts[3] child-pointer loads of the leaf lookups (tree marcher only)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_counts(unsigned long long (&c)[4], unsigned long long* __restrict__ counts) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned long long v = c[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + i, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void octree_count_kernel(RenderArgs A, unsigned long long* __restrict__ counts,
+                                                           uint8_t* __restrict__ leaf_seen) {
+  __shared__ int s_stack[256][kMaxD + 2];
+  unsigned long long c[4] = {0, 0, 0, 0};
+  const int W = A.cam.width, H = A.cam.height;
+  const int64_t ray = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (ray < (int64_t)W * H) {
+    float origin[3], dir[3];
+    camera_ray(A.cam.c2w, A.cam.fx, A.cam.fy, W, H, (int)(ray % W), (int)(ray / W), origin, dir);
+    TreeRay r;
+    to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
+    CellExit cell_exit;
+    cell_exit.init(r.invdir);
+    if (!(r.tmax < 0.0f || r.tmin > r.tmax)) {
+      c[0] = 1;
+      const int D = A.tree.data_dim;
+      const float* __restrict__ data = A.tree.data;
+      const int32_t* __restrict__ child = A.tree.child;
+      Marcher mk;
+      mk.init(s_stack[threadIdx.x]);
+      float t = r.tmin, light = 1.0f;
+      while (t < r.tmax) {
+        float pos[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + t * r.d[a]);
+        int depth;
+        const int64_t leaf = mk.find(child, pos, depth);
+        c[3] += (unsigned long long)mk.loads;
+        const float cube = (float)(2u << depth);
+        float local[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) local[a] = __builtin_amdgcn_fractf(pos[a] * cube);
+        const float delta_t = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
+        const float sg = data[leaf * D + D - 1];
+        c[1] += 1;
+        if (sg > A.opt.sigma_thresh) {
+          c[2] += 1;
+          if (leaf_seen) leaf_seen[leaf] = 1;
+          light = light * expf(-(delta_t * r.delta_scale) * sg);
+          if (light <= A.opt.stop_thresh) break;
+        }
+        const float tn = t + delta_t;
+        if (!(tn > t)) break;
+        t = tn;
+      }
+    }
+  }
+  flush_counts(c, counts);
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ sigma, int reso, const float* __restrict__ c2w_all,
+                                                         int n_cams, float fx, float fy, int W, int H, PxoRenderOpts opt,
+                                                         Vec3 offset, Vec3 invradius, unsigned long long* __restrict__ counts,
+                                                         uint8_t* __restrict__ voxel_seen) {
+  unsigned long long c[4] = {0, 0, 0, 0};
+  const int64_t id = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int64_t hw = (int64_t)W * H;
+  if (id < hw * n_cams) {
+    const int cam = (int)(id / hw);
+    const int64_t pix = id % hw;
+    float origin[3], dir[3];
+    camera_ray(c2w_all + (int64_t)cam * 12, fx, fy, W, H, (int)(pix % W), (int)(pix / W), origin, dir);
+    TreeRay r;
+    to_tree_ray(origin, dir, offset.v, invradius.v, r);
+    if (!(r.tmax < 0.0f || r.tmin > r.tmax)) {
+      c[0] = 1;
+      const float cube = (float)reso;
+      CellExit cell_exit;
+      cell_exit.init(r.invdir);
+      float t = r.tmin, light = 1.0f;
+      while (t < r.tmax) {
+        float local[3];
+        int cc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float p = clamp_coord(r.o[a] + t * r.d[a]) * cube;
+          cc[a] = (int)p;
+          local[a] = __builtin_amdgcn_fractf(p);
+        }
+        const float delta_t = cell_exit(local) / cube + opt.step_size;     // reso a power of two: the exact quotient either way
+        const int64_t idx = ((int64_t)cc[0] * reso + cc[1]) * reso + cc[2];
+        const float sg = sigma[idx];
+        c[1] += 1;
+        if (sg > opt.sigma_thresh) {
+          c[2] += 1;
+          if (voxel_seen) voxel_seen[idx] = 1;
+          light = light * expf(-(delta_t * r.delta_scale) * sg);
+          if (light <= opt.stop_thresh) break;
+        }
+        const float tn = t + delta_t;
+        if (!(tn > t)) break;
+        t = tn;
+      }
+    }
+  }
+  flush_counts(c, counts);
+}
+
+// ------------------------------------------------------------------------------------------
 // image loss and SGD
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void image_mse_kernel(const float* __restrict__ im, const float* __restrict__ gt, int64_t n,
@@ -1609,6 +1726,34 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
     default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
   }
   return check_launch("octree_render_bwd");
+}
+
+int pxo_octree_count_work(const PxoTree* tree, const PxoCamera* cam, const PxoRenderOpts* opts, unsigned long long* counts,
+                          uint8_t* leaf_seen, void* stream) {
+  PXO_REQUIRE(cam != nullptr && counts != nullptr, "pxo_octree_count_work: needs a camera and a counts[4] buffer");
+  RenderArgs A;
+  unsigned grid;
+  int row;
+  if (int rc = render_args(tree, cam, nullptr, nullptr, nullptr, (int64_t)cam->width * cam->height, opts,
+                           "pxo_octree_count_work", false, A, grid, row)) return rc;
+  const int64_t rays = (int64_t)cam->width * cam->height;
+  hipLaunchKernelGGL(octree_count_kernel, dim3((unsigned)blocks_for(rays, 256)), dim3(256), 0, (hipStream_t)stream, A, counts,
+                     leaf_seen);
+  return check_launch("octree_count_work");
+}
+
+int pxo_grid_weight_count_work(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
+                               int width, int height, const PxoRenderOpts* opts, const float offset[3],
+                               const float invradius[3], unsigned long long* counts, uint8_t* voxel_seen, void* stream) {
+  if (int rc = check_opts(opts, "pxo_grid_weight_count_work")) return rc;
+  PXO_REQUIRE(sigma_grid && c2w_all && offset && invradius && counts && reso >= 1 && n_cams >= 1 && width >= 1 && height >= 1,
+              "pxo_grid_weight_count_work: bad arguments");
+  Vec3 o, ir;
+  for (int a = 0; a < 3; ++a) { o.v[a] = offset[a]; ir.v[a] = invradius[a]; }
+  const int64_t rays = (int64_t)width * height * n_cams;
+  hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)blocks_for(rays, 256)), dim3(256), 0, (hipStream_t)stream, sigma_grid, reso,
+                     c2w_all, n_cams, fx, fy, width, height, *opts, o, ir, counts, voxel_seen);
+  return check_launch("grid_weight_count_work");
 }
 
 int pxo_image_mse(const float* im, const float* gt, int64_t n, float* grad, float* sse_out, void* stream) {

@@ -60,11 +60,11 @@ int validate_cfg(const PxoCfg* cfg) {
 
 // ---- HIP-event profiler ------------------------------------------------------------------
 struct ProfRecord { hipEvent_t a, b; int tag; int64_t rows; };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;              // bit t set: launches tagged t are bracketed by events
 static std::vector<ProfRecord> g_prof;
 
 KernelTimer::KernelTimer(int tag, int64_t rows, hipStream_t s) : slot(-1), stream(s) {
-  if (!g_prof_on) return;
+  if (!((g_prof_mask >> tag) & 1u)) return;
   ProfRecord r;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.tag = tag; r.rows = rows;
@@ -609,8 +609,10 @@ int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, con
                           packed_bwd1, (hipStream_t)stream);
 }
 
-int pxo_profile_enable(int on) {
-  g_prof_on = on != 0;
+int pxo_profile_enable(int tag_mask) {
+  PXO_REQUIRE(tag_mask >= 0 && tag_mask < (1 << PXO_PROF_NUM_TAGS), "pxo_profile_enable: mask %d has bits beyond the %d tags",
+              tag_mask, PXO_PROF_NUM_TAGS);
+  g_prof_mask = (unsigned)tag_mask;
   return PXO_OK;
 }
 

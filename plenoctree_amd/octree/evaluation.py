@@ -29,6 +29,10 @@ def define_flags():
 def main(argv=None):
     args = define_flags().parse_args(argv)
     utils.update_flags(args)
+    if args.write_vid is not None and os.path.splitext(args.write_vid)[1].lower() != ".gif":
+        # checked BEFORE anything is rendered: imageio / ffmpeg are not installed, so only the animated GIF writer is built
+        raise ValueError(f"--write_vid {args.write_vid}: only animated GIF output is built (no imageio/ffmpeg here); "
+                         "give a .gif path")
     if not torch.cuda.is_available():
         raise SystemExit("octree.evaluation needs a ROCm GPU; the HIP path has no CPU fallback")
     comm = dist.init_from_env()
@@ -45,9 +49,6 @@ def main(argv=None):
     if args.write_vid is not None and frames:
         # imageio / ffmpeg are not installed: this rank's frames (every world-th view) as an animated GIF
         from PIL import Image
-        if os.path.splitext(args.write_vid)[1].lower() != ".gif":
-            raise ValueError(f"--write_vid {args.write_vid}: only animated GIF output is built (no imageio/ffmpeg here); "
-                             "give a .gif path")
         path = args.write_vid if comm.world == 1 else os.path.splitext(args.write_vid)[0] + f".rank{comm.rank}.gif"
         print("Writing to", path, flush=True)
         ims = [Image.fromarray(im.numpy()) for _, im in frames]

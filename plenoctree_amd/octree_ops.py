@@ -181,6 +181,35 @@ def octree_render_persp_bwd(tree, c2w, width, height, fx, opts, grad_out, grad_d
     return grad_data
 
 
+def octree_count_work(tree, c2w, width, height, fx, opts, fy=None, count_leaves=True):
+    """Work counters of one render of `tree` from camera c2w (pxo_octree_count_work: the renderer's own march, counting):
+    dict(rays, samples, shaded_samples, child_loads, distinct_leaves).  A roofline / debug pass, not on the product path."""
+    _require_gpu()
+    cam, keep = _camera(c2w, width, height, fx, fy)
+    counts = torch.zeros(4, dtype=torch.int64, device=keep.device)
+    seen = torch.zeros(tree.n_internal * 8, dtype=torch.uint8, device=keep.device) if count_leaves else None
+    check(_lib.load().pxo_octree_count_work(ctypes.byref(tree), ctypes.byref(cam), ctypes.byref(opts), _p(counts), _p(seen),
+                                            _stream()), "pxo_octree_count_work")
+    c = counts.tolist()
+    return {"rays": c[0], "samples": c[1], "shaded_samples": c[2], "child_loads": c[3],
+            "distinct_leaves": int(seen.sum(dtype=torch.int64)) if count_leaves else None}
+
+
+def grid_weight_count_work(sigma_grid, reso, c2w_all, fx, fy, width, height, opts, offset, invradius, count_voxels=True):
+    """Work counters of pxo_grid_weight_render on the same cameras: dict(rays, samples, occupied_samples, distinct_voxels)."""
+    _require_gpu()
+    dev = sigma_grid.device
+    c2w = c2w_all[:, :3, :4].contiguous().to(device=dev, dtype=torch.float32)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    seen = torch.zeros(reso ** 3, dtype=torch.uint8, device=dev) if count_voxels else None
+    check(_lib.load().pxo_grid_weight_count_work(_f(sigma_grid.reshape(-1)), reso, _f(c2w), c2w.shape[0], float(fx), float(fy),
+                                                 int(width), int(height), ctypes.byref(opts), _vec3(offset), _vec3(invradius),
+                                                 _p(counts), _p(seen), _stream()), "pxo_grid_weight_count_work")
+    c = counts.tolist()
+    return {"rays": c[0], "samples": c[1], "occupied_samples": c[2],
+            "distinct_voxels": int(seen.sum(dtype=torch.int64)) if count_voxels else None}
+
+
 def octree_render_rays(tree, origins, dirs, viewdirs, opts):
     """[B,3] colours of explicit world-space rays with unit dirs (VolumeRenderer.forward)."""
     _require_gpu()

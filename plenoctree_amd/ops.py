@@ -334,8 +334,19 @@ def grid_sigma(cfg, packed_fwd, reso, x0, x1, offset, scale, out=None):
     return out
 
 
-def profile_enable(on=True):
-    check(_lib.load().pxo_profile_enable(int(on)), "pxo_profile_enable")
+PROF_MLP_FWD, PROF_MLP_BWD_DATA, PROF_WGRAD_MAIN, PROF_WGRAD_OTHER, PROF_NUM_TAGS = 0, 1, 2, 3, 4
+
+
+def profile_enable(on=True, tags=None):
+    """HIP-event brackets around the tagged kernel launches: all tags (on=True), none (False), or the listed `tags`.
+    Every bracket costs the stream two event records (~5 us each between kernels that would otherwise run back to back)."""
+    mask = 0
+    if tags is not None:
+        for t in tags:
+            mask |= 1 << int(t)
+    elif on:
+        mask = (1 << PROF_NUM_TAGS) - 1
+    check(_lib.load().pxo_profile_enable(mask), "pxo_profile_enable")
 
 
 def profile_read(tag):

@@ -2,8 +2,20 @@
 """Timing of the PlenOctree-side kernels at the reference's sizes (init_grid_depth 8 -> 512^3 grid, 800x800
 views) on an analytic scene: three fuzzy spheres' density on the grid, random SH16 coefficients in the leaves.
 
-Prints one JSON line with per-kernel times and achieved algorithmic rates (rays/s, leaf visits/s, GB/s of leaf
-data touched).  Secondary measurement for DESIGN.md -- bench.py's headline stays the training metric.
+Prints one JSON line with per-kernel times and, per kernel, a recomputable ROOFLINE ("HBM-bound
+pointer-chasing kernel ... different roofline from (a)"): the work counters of pxo_octree_count_work /
+pxo_grid_weight_count_work (the kernels' own march, counting) give
+
+  algorithmic bytes = what the kernel must move if nothing were cached: a D-float leaf row per sample above the sigma
+                      threshold (196 B for SH16), 4 B of sigma per other sample, 4 B per child pointer of the leaf
+                      lookups, 12 B per ray of output (+ for the backward: grad_out and the forward image, 24 B per ray,
+                      and every touched gradient row read-modify-written once, 2 x 196 B per DISTINCT leaf)
+  hbm floor bytes   = the same with every leaf row fetched ONCE per launch (distinct leaves x 196 B): what a perfect cache
+                      would still have to read from HBM
+  achieved          = algorithmic bytes / measured time, against PEAK_HBM_ACHIEVABLE = 6.3 TB/s
+                      (MI355X_MICROARCH.md: achievable HBM3E rate; nominal 8 TB/s)
+
+Secondary measurement for DESIGN.md -- bench.py's headline stays the training metric.
 """
 import argparse
 import json
@@ -30,6 +42,16 @@ def timed(fn, reps=3):
     return a.elapsed_time(b) / reps
 
 
+PEAK_HBM_ACHIEVABLE_GBPS = 6300.0
+
+
+def roofline(alg_bytes, floor_bytes, ms, parts):
+    gbps = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "algorithmic_bytes": alg_bytes, "hbm_floor_bytes": floor_bytes, "ms": ms, "achieved": gbps,
+            "peak": PEAK_HBM_ACHIEVABLE_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_ACHIEVABLE_GBPS,
+            "frac_of_hbm_floor": floor_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_ACHIEVABLE_GBPS, "per_image": parts}
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--depth", type=int, default=8)
@@ -39,6 +61,7 @@ def main():
     p.add_argument("--basis", type=int, default=16, help="SH basis_dim of the tree data (16 or 25)")
     p.add_argument("--gw-only", action="store_true", help="stop after grid_weight_render (A/B of that kernel)")
     p.add_argument("--hard", action="store_true", help="exact zeros outside the spheres (as a trained, relu'd density has) instead of fuzzy tails")
+    p.add_argument("--no-roofline", action="store_true", help="skip the counting passes")
     a = p.parse_args()
     from plenoctree_amd import build, octree_ops as oops
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
@@ -69,6 +92,16 @@ def main():
     ms = timed(lambda: oops.grid_weight_render(sig, reso, cams, focal, focal, W, H, opts, tree.offset, tree.invradius, grid_weight=wt), reps=1)
     out["grid_weight_render_ms_per_cam"] = ms / a.cams
     out["grid_weight_Mrays_per_s"] = a.cams * W * H / ms / 1e3
+    if not a.no_roofline:
+        c = oops.grid_weight_count_work(sig, reso, cams, focal, focal, W, H, opts, tree.offset, tree.invradius)
+        n = a.cams
+        per = {"rays": c["rays"] / n, "samples": c["samples"] / n, "occupied_samples": c["occupied_samples"] / n,
+               "distinct_voxels_all_cams": c["distinct_voxels"], "brick_passes_bytes": 4 * reso ** 3 * 4 / n}
+        # sigma: 4 B per sample; weights: every touched voxel read-modify-written once per call; bricking sigma and
+        # unbricking the weights stream the grid 4 times per call (amortised over the call's cameras)
+        alg = per["samples"] * 4 + c["distinct_voxels"] * 8 / n + per["brick_passes_bytes"]
+        floor = (min(c["distinct_voxels"] * 4 + c["distinct_voxels"] * 8, reso ** 3 * 12)) / n + per["brick_passes_bytes"]
+        out["grid_weight_roofline"] = roofline(alg, floor, ms / a.cams, per)
     mask = oops.threshold_mask(wt, 1e-3)
     out["mask_voxels"] = int(mask.sum())
     out["weight_sum"] = float(wt.double().sum())
@@ -92,6 +125,8 @@ def main():
     leaf.copy_(torch.randn(leaf.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 0.5)
     leaf[:, -1] = sig[(idx[:, 0] * reso + idx[:, 1]) * reso + idx[:, 2]]
     r = VolumeRenderer(tree, step_size=a.step)
+    counts = {}
+
     def render_all(fast):
         with torch.no_grad():
             return [r.render_persp(c, width=W, height=H, fx=focal, fast=fast) for c in cams]
@@ -102,6 +137,14 @@ def main():
         out[f"render_{key}_ms_per_image"] = ms
         out[f"render_{key}_Mrays_per_s"] = W * H / ms / 1e3
         out[f"render_{key}_fps"] = 1e3 / ms
+        if not a.no_roofline:
+            cs = [oops.octree_count_work(tree.view(), c, W, H, focal, r._opts(fast)) for c in cams]
+            avg = {k: sum(x[k] for x in cs) / len(cs) for k in cs[0]}
+            D = tree.data_dim
+            alg = avg["shaded_samples"] * D * 4 + (avg["samples"] - avg["shaded_samples"]) * 4 + avg["child_loads"] * 4 + W * H * 12
+            floor = avg["distinct_leaves"] * D * 4 + W * H * 12
+            out[f"render_{key}_roofline"] = roofline(alg, floor, ms, avg)
+            counts[key] = (avg, alg, floor)
     with torch.no_grad():
         im = r.render_persp(cams[0], width=W, height=H, fx=focal)
     out["image_mean"] = float(im.mean())
@@ -120,6 +163,15 @@ def main():
         key = "render_bwd_reusing_fwd" if reuse else "render_bwd"
         out[f"{key}_ms_per_image"] = ms
         out[f"{key}_Mrays_per_s"] = W * H / ms / 1e3
+        if "exact" in counts:
+            # the backward marches exactly (no early stop): the exact forward's reads per march (two marches without the
+            # kept image), + grad_out and the forward image per ray, + every touched gradient row read-modify-written once
+            avg, alg_f, floor_f = counts["exact"]
+            D = tree.data_dim
+            marches = 1 if reuse else 2
+            extra = W * H * (24 if reuse else 12) + avg["distinct_leaves"] * D * 4 * 2
+            out[f"{key}_roofline"] = roofline(marches * (alg_f - W * H * 12) + extra, floor_f - W * H * 12 + extra, ms,
+                                              dict(avg, marches=marches))
     out["grad_abs_sum"] = float(grad.double().abs().sum())
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
     out["tree_data_MB"] = tree.data.numel() * 4 / 1e6

@@ -81,7 +81,7 @@ def install():
     ops.render_fwd, ops.grid_sigma = render_fwd, grid_sigma
     ops.train_workspace_bytes = lambda pcfg, B: 16
     ops.render_workspace_bytes = lambda pcfg, B: 16
-    ops.profile_enable = lambda on=True: prof.__setitem__("on", bool(on))
+    ops.profile_enable = lambda on=True, tags=None: prof.__setitem__("on", bool(on) if tags is None else bool(tags))
     ops.profile_read = lambda tag: (0, 0.0, 0)
 
     def render_opts(step_size=1e-3, background_brightness=1.0, sigma_thresh=0.0, stop_thresh=0.0):

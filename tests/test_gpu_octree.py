@@ -197,6 +197,81 @@ def test_octree_render_matches_oracle(K):
     assert np.allclose(want[-1], 0.5) and torch.allclose(got[-1].cpu(), torch.full((3,), 0.5))
 
 
+def test_work_counters_match_the_oracle_march():
+    """pxo_octree_count_work / pxo_grid_weight_count_work (the roofline pass of scripts/octree_bench.py) repeat the kernels'
+    march and count; the oracle's literal march (march_tree / grid_weight_render's loop) gives the same integers: rays that
+    enter the volume, samples, samples above the sigma threshold (with the early stop of the `fast` preset), distinct leaves;
+    child-pointer loads lie between one per sample (full path reuse) and depth + 1 per sample (none)."""
+    oops = _oops(); dev = _gpu()
+    t = _random_tree(3, 21, 4)
+    view, keep = _device_tree(t, dev)
+    W, H, fx = 14, 10, 13.0
+    flat = t.data.reshape(-1, t.data_dim)
+    for theta, phi, fast in ((20.0, 30.0, False), (250.0, -5.0, True)):
+        c2w = _pose(theta, phi)
+        opt = T.RenderOptions.for_renderer(1e-3, fast)
+        rays = samples = shaded = 0
+        leaves = set()
+        for iy in range(H):
+            for ix in range(W):
+                o, d = T.cam2world_ray(ix, iy, c2w, W, H, fx, fx)
+                seq = T.march_tree(t, o, d, opt)
+                if seq is None:
+                    continue
+                rays += 1
+                light = f32(1.0)
+                for leaf, dtw in seq:
+                    samples += 1
+                    sg = flat[leaf][-1]
+                    if sg > opt.sigma_thresh:
+                        shaded += 1
+                        leaves.add(leaf)
+                        light = f32(light * f32(np.exp(f32(-dtw * sg), dtype=f32)))
+                        if light <= opt.stop_thresh:
+                            break
+        got = oops.octree_count_work(view, torch.from_numpy(c2w).to(dev), W, H, fx,
+                                     oops.render_opts(1e-3, 1.0, float(opt.sigma_thresh), float(opt.stop_thresh)))
+        assert (got["rays"], got["samples"], got["shaded_samples"], got["distinct_leaves"]) == (rays, samples, shaded, len(leaves)), \
+            (got, rays, samples, shaded, len(leaves))
+        assert samples <= got["child_loads"] <= samples * 4 and samples > 500
+    # the weight mask's march on a dense grid
+    reso = 16
+    sigma = ((np.random.RandomState(0).rand(reso, reso, reso) - 0.6) * 30.0).astype(f32)
+    cams = np.stack([_pose(20.0, 30.0), _pose(200.0, -10.0)])
+    opt = T.RenderOptions(step_size=1e-3)
+    rays = samples = occ = 0
+    seen = np.zeros_like(sigma, dtype=bool)
+    for c in cams:
+        for iy in range(11):
+            for ix in range(13):
+                origin, direction = T.cam2world_ray(ix, iy, c, 13, 11, 14.0, 14.0)
+                o, d, invdir, delta_scale = T._to_tree_ray(origin, direction, t.offset, t.invradius)
+                tmin, tmax = T._dda_unit(o, invdir)
+                if tmax < 0 or tmin > tmax:
+                    continue
+                rays += 1
+                tt, light = tmin, f32(1.0)
+                while tt < tmax:
+                    pos = np.clip(np.array([f32(o[a] + f32(tt * d[a])) for a in range(3)], f32), f32(0.0), f32(1.0 - 1e-6)).astype(f32)
+                    pos = (pos * f32(reso)).astype(f32)
+                    u = np.floor(pos).astype(np.int64)
+                    s0, s1 = T._dda_unit((pos - u.astype(f32)).astype(f32), invdir)
+                    delta_t = f32(f32(f32(s1 - s0) / f32(reso)) + opt.step_size)
+                    samples += 1
+                    sg = sigma[u[0], u[1], u[2]]
+                    if sg > opt.sigma_thresh:
+                        occ += 1
+                        seen[u[0], u[1], u[2]] = True
+                        light = f32(light * f32(np.exp(f32(-f32(delta_t * delta_scale) * sg), dtype=f32)))
+                        if light <= opt.stop_thresh:
+                            break
+                    tt = f32(tt + delta_t)
+    got = oops.grid_weight_count_work(torch.from_numpy(sigma).to(dev), reso, torch.from_numpy(cams).to(dev), 14.0, 14.0, 13, 11,
+                                      oops.render_opts(1e-3), t.offset, t.invradius)
+    assert (got["rays"], got["samples"], got["occupied_samples"], got["distinct_voxels"]) == (rays, samples, occ, int(seen.sum())), \
+        (got, rays, samples, occ, int(seen.sum()))
+
+
 @pytest.mark.parametrize("K", [4, 16, 25])
 def test_octree_render_gradient_matches_oracle(K):
     oops = _oops(); dev = _gpu()

@@ -263,6 +263,11 @@ def main():
     out["grad"] = g["f64"].astype(f32)                     # float64 AD rounded once to float32 (4 MB)
     out["grad_norm_f64"] = np.float64(np.linalg.norm(g["f64"]))
     out["grad_f32_vs_f64_rel_l2"] = np.float64(rel)
+    n = g["f64"].size // 2
+    for mi in range(2):                                    # the same per MLP: the float32 noise floor of a 24-ray step
+        a, b = g["f32"][mi * n:(mi + 1) * n], g["f64"][mi * n:(mi + 1) * n]
+        out[f"grad_f32_vs_f64_rel_l2_mlp{mi}"] = np.float64(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"  MLP_{mi}: reference-f32 vs reference-f64 rel L2 {float(out[f'grad_f32_vs_f64_rel_l2_mlp{mi}']):.3e}")
     np.savez_compressed(os.path.join(HERE, "train_grad.npz"), **out)
     print("wrote", os.path.join(HERE, "train_grad.npz"))
 

@@ -202,12 +202,13 @@ def test_train_stats_against_reference_loss_fn(golden_dir):
 
 def test_train_gradient_against_reference_autograd(golden_dir):
     """G1.  train_grad.npz: float64 reverse-mode AD through the reference's loss_fn body (make_golden_grad.py), 24 rays,
-    500 sparsity points, weight decay on.  Bounds, relative L2 over each MLP's sub-arena:
-      MLP_0 (coarse: positions do not depend on the parameters)                  <= 3e-4   (float32 GEMM chains)
-      MLP_1 (fine: positions from the float32 inverse CDF, condition number ~1e4) <= 3 x the reference's OWN float32
-             evaluation's distance from its float64 one, which the fixture records (8.8e-4)
-    and every one of the 40 leaves within 10x its MLP's bound (a wrong small leaf cannot hide in the norm).
-    Stats against the float64 run: rel 2e-5."""
+    500 sparsity points, weight decay on.  A 24-ray step in float32 is noisy (a pre-activation within round-off of 0 takes
+    either ReLU branch; the fine positions come from a float32 inverse CDF with a condition number of ~1e4): the REFERENCE'S
+    OWN float32 evaluation is 7.1e-4 (MLP_0) / 9.9e-4 (MLP_1) relative L2 away from its float64 one, both recorded in the
+    fixture.  Bounds, relative L2 over each MLP's sub-arena against the float64 gradient: <= 2 x that float32 noise floor
+    (measured 9.8e-4 / 1.06e-3), and every one of the 40 leaves within 10 x its MLP's bound (a wrong small leaf cannot hide
+    in the norm).  At 4096 rays the same comparison against the oracle is held to 2e-3 / measured 0.9e-4 and 0.9e-3
+    (tests/test_gpu_fullsize.py).  Stats against the float64 run: rel 2e-5."""
     ops = _ops(); dev = _gpu()
     g = np.load(os.path.join(golden_dir, "train_grad.npz"))
     gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
@@ -216,11 +217,11 @@ def test_train_gradient_against_reference_autograd(golden_dir):
     want = torch.tensor(g["grad"]).double()
     got = grad.double()
     n = want.numel() // 2
-    ref32 = float(g["grad_f32_vs_f64_rel_l2"])
-    bounds = (3e-4, 3 * ref32)
+    ref32 = (float(g["grad_f32_vs_f64_rel_l2_mlp0"]), float(g["grad_f32_vs_f64_rel_l2_mlp1"]))
+    bounds = (2 * ref32[0], 2 * ref32[1])
     rels = [float((got[i * n:(i + 1) * n] - want[i * n:(i + 1) * n]).norm() / want[i * n:(i + 1) * n].norm()) for i in range(2)]
     print(f"HIP vs reference-autograd gradient: MLP_0 rel L2 {rels[0]:.2e}, MLP_1 {rels[1]:.2e} "
-          f"(reference f32 vs f64 over both: {ref32:.2e})")
+          f"(the reference's own float32 evaluation: {ref32[0]:.2e} / {ref32[1]:.2e})")
     assert rels[0] <= bounds[0] and rels[1] <= bounds[1], rels
     off = 0
     for mi in range(2):

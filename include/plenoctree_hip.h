@@ -62,6 +62,8 @@ typedef struct PxoCfg {
   float sparsity_radius;       /* 1.5 */
   float weight_decay_mult;     /* 0 */
   int32_t mlp_precision;       /* PXO_MLP_F32 (0, default) or PXO_MLP_BF16X3: INFERENCE-ONLY opt-in, see below */
+  float noise_std;             /* 0 = the reference's None (every preset); > 0: add_gaussian_noise on raw sigma of the ray
+                                  samples when randomized (nerf_sh/nerf/models.py:258-264,318-324) */
 } PxoCfg;
 
 /* PxoCfg.mlp_precision.  PXO_MLP_F32: exact float32 MFMA everywhere (the reference's precision; training and every
@@ -169,6 +171,16 @@ int pxo_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const flo
 int pxo_sample_pdf(const float* z_coarse, const float* w_coarse, const float* origins,
                    const float* directions, int64_t B, int Nc, int Nf, const float* u,
                    float* z_out, float* pts, void* stream);
+
+/* add_gaussian_noise (nerf_sh/nerf/model_utils.py:317-332; call sites nerf_sh/nerf/models.py:258-264,318-324, between the
+ * MLP and the sigma activation): raw[i] += noise_std * n_i in place, i < n.  noise [n]: explicit standard-normal draws
+ * (parity runs: the jax key replaced by its draw) or NULL: n_i from Philox stream (seed, stream_id) by Box-Muller
+ * (block q = counter, words (0,1) -> elements 4q, 4q+1, words (2,3) -> 4q+2, 4q+3; u1 = ((w >> 8) + 1) / 2^24 in (0,1],
+ * u2 = (w' >> 8) / 2^24: z = sqrt(-2 ln u1) (cos, sin)(2 pi u2)).  The whole-path entry points apply it to the raw sigma of
+ * the ray samples (streams 3 = coarse, 4 = fine) when PxoCfg.noise_std > 0 and randomized != 0 -- the reference's
+ * `(noise_std is not None) and randomized`; the sparsity points (eval_points_raw) get none, as in the reference. */
+int pxo_add_gaussian_noise(float* raw, int64_t n, float noise_std, const float* noise, uint64_t seed,
+                           uint64_t stream_id, void* stream);
 
 /* Counter-based uniform generator (Philox4x32-10) replacing jax.random.uniform call sites
  * (nerf_sh/nerf/model_utils.py:135,262; nerf_sh/train.py:79).  out[i] in [lo,hi). */

@@ -21,6 +21,9 @@ Parity status
   the reference's models.py + its MLP run through the shim with a dataclass stub of
   flax.linen.Module and a Dense stub fed the weights in flax's creation order
   (tests/golden/nerf_model.npz).
+* add_gaussian_noise and its place in the composition (raw sigma, before the relu, separate draws for the two
+  levels) are PINNED the same way with noise_std = 0.3 and injected normals (tests/golden/nerf_model_noise.npz,
+  written by make_golden_grad.py's torch-backed shim).
 * loss_fn's VALUE and Stats are PINNED against the reference's own train_step
   (nerf_sh/train.py:51-121) run through the shim with value_and_grad evaluating
   the function only (tests/golden/train_loss.npz).
@@ -74,6 +77,7 @@ class Cfg:
         self.sparsity_radius = 1.5
         self.sparsity_npoints = 10000
         self.weight_decay_mult = 0.0
+        self.noise_std = None            # nerf_sh/nerf/utils.py:137-140 (no preset sets it)
         self.lr_init = 5e-4
         self.lr_final = 5e-6
         self.max_steps = 2000000
@@ -326,9 +330,18 @@ def eval_points_raw(params, points, cfg, coarse=False):
     return raw_rgb[0], raw_sigma[0]
 
 
-def _shade(mlp, samples, viewdirs, cfg):
+def add_gaussian_noise(raw, noise_std, noise):
+    """nerf_sh/nerf/model_utils.py:317-332: raw + normal * noise_std when noise_std is not None and randomized;
+    `noise` (shaped like raw) replaces random.normal(key, raw.shape), None means randomized=False."""
+    if noise_std is not None and noise is not None:
+        return raw + noise.reshape(raw.shape) * noise_std
+    return raw
+
+
+def _shade(mlp, samples, viewdirs, cfg, noise=None):
     enc = posenc(samples, cfg.min_deg_point, cfg.max_deg_point)
     raw_rgb, raw_sigma = mlp_forward(mlp, enc, cfg)
+    raw_sigma = add_gaussian_noise(raw_sigma, cfg.noise_std, noise)      # models.py:258-264 / :318-324
     # models.py:269-272: reshape(..., 3, K) then eval_sh with viewdirs[:, None]
     raw = eval_sh(cfg.sh_deg, raw_rgb.reshape(*raw_rgb.shape[:-1], -1, cfg.sh_dim),
                   viewdirs[:, None])
@@ -337,13 +350,14 @@ def _shade(mlp, samples, viewdirs, cfg):
     return rgb, sigma, raw_rgb, raw_sigma
 
 
-def render(params, rays, cfg, t_rand=None, u=None, return_aux=False):
-    """NerfModel.__call__, nerf_sh/nerf/models.py:216-348 (sh_deg>=0, no viewdirs,
-    noise_std=None). Returns [(rgb,disp,acc)_coarse, (rgb,disp,acc)_fine]."""
+def render(params, rays, cfg, t_rand=None, u=None, return_aux=False, noise_c=None, noise_f=None):
+    """NerfModel.__call__, nerf_sh/nerf/models.py:216-348 (sh_deg>=0, no viewdirs).  noise_c [B,Nc] / noise_f [B,Nc+Nf]:
+    the standard-normal draws of add_gaussian_noise when cfg.noise_std is set (None = randomized False).
+    Returns [(rgb,disp,acc)_coarse, (rgb,disp,acc)_fine]."""
     aux = {}
     z_vals, samples = sample_along_rays(rays.origins, rays.directions, cfg.num_coarse_samples,
                                         cfg.near, cfg.far, t_rand, cfg.lindisp)
-    rgb, sigma, raw_rgb, raw_sigma = _shade(params[0], samples, rays.viewdirs, cfg)
+    rgb, sigma, raw_rgb, raw_sigma = _shade(params[0], samples, rays.viewdirs, cfg, noise_c)
     comp_rgb, disp, acc, weights = volumetric_rendering(rgb, sigma, z_vals, rays.directions,
                                                         cfg.white_bkgd)
     ret = [(comp_rgb, disp, acc)]
@@ -352,7 +366,7 @@ def render(params, rays, cfg, t_rand=None, u=None, return_aux=False):
         z_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])           # models.py:296
         z_vals, samples = sample_pdf(z_mid, weights[..., 1:-1], rays.origins, rays.directions,
                                      z_vals, cfg.num_fine_samples, u)  # models.py:298-307
-        rgb, sigma, raw_rgb, raw_sigma = _shade(params[1], samples, rays.viewdirs, cfg)
+        rgb, sigma, raw_rgb, raw_sigma = _shade(params[1], samples, rays.viewdirs, cfg, noise_f)
         comp_rgb, disp, acc, weights = volumetric_rendering(rgb, sigma, z_vals, rays.directions,
                                                             cfg.white_bkgd)
         ret.append((comp_rgb, disp, acc))

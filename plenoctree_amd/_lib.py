@@ -40,6 +40,7 @@ class PxoCfg(Structure):
         ("sparsity_radius", c_float),
         ("weight_decay_mult", c_float),
         ("mlp_precision", c_int32),
+        ("noise_std", c_float),
     ]
 
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     "pxo_shade_composite_bwd": (c_int, [CFG, P, P, P, P, P, P, c_int64, c_int, P, P, P]),
     "pxo_shade_composite_train": (c_int, [CFG, P, P, P, P, P, P, c_int64, c_int, P, P, P, P, P, c_int64, P, P]),
     "pxo_sample_pdf": (c_int, [P, P, P, P, c_int64, c_int, c_int, P, P, P, P]),
+    "pxo_add_gaussian_noise": (c_int, [P, c_int64, c_float, P, c_uint64, c_uint64, P]),
     "pxo_uniform": (c_int, [c_uint64, c_uint64, c_int64, c_float, c_float, P, P]),
     "pxo_randint": (c_int, [c_uint64, c_uint64, c_int64, c_int64, P, P]),
     "pxo_generate_rays": (c_int, [P, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
@@ -184,7 +186,7 @@ def make_cfg(**kw):
     vals = dict(num_coarse_samples=64, num_fine_samples=128, sh_deg=3, min_deg_point=0, max_deg_point=10,
                 white_bkgd=1, lindisp=0, sparsity_npoints=10000, near_=2.0, far_=6.0,
                 sparsity_weight=1e-3, sparsity_length=0.05, sparsity_radius=1.5, weight_decay_mult=0.0,
-                mlp_precision=0)
+                mlp_precision=0, noise_std=0.0)
     for k, v in kw.items():
         if k not in vals:
             raise ValueError(f"unknown PxoCfg field {k}")
@@ -192,5 +194,5 @@ def make_cfg(**kw):
     cfg = PxoCfg()
     for k, v in vals.items():
         setattr(cfg, k, int(v) if k not in ("near_", "far_", "sparsity_weight", "sparsity_length",
-                                            "sparsity_radius", "weight_decay_mult") else float(v))
+                                            "sparsity_radius", "weight_decay_mult", "noise_std") else float(v))
     return cfg

@@ -55,6 +55,7 @@ int validate_cfg(const PxoCfg* cfg) {
               "num_coarse_samples+num_fine_samples must be <= 256");
   PXO_REQUIRE(cfg->mlp_precision == PXO_MLP_F32 || cfg->mlp_precision == PXO_MLP_BF16X3, "mlp_precision %d unknown",
               cfg->mlp_precision);
+  PXO_REQUIRE(cfg->noise_std >= 0.f, "noise_std %g < 0 (0 = None)", (double)cfg->noise_std);
   return PXO_OK;
 }
 
@@ -228,7 +229,7 @@ static void carve_train(const PxoCfg* cfg, int64_t B, void* ws, bool train, Trai
 // the coarse level between the levels.  pixels != nullptr selects the training form: compositing, the pixel loss and its
 // reverse in one kernel per pass (d_raw_* and ray_sse are written, the rgb/disp/acc outputs are not), with the sparsity
 // rows of the last pass served by the same launch.
-struct Draws { const float* t_rand; const float* u; };
+struct Draws { const float* t_rand; const float* u; bool noisy; uint64_t seed; };
 
 // every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
 static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomized, const float* t_rand, const float* u,
@@ -252,6 +253,8 @@ static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomize
     }
   }
   out.t_rand = t_rand; out.u = u;
+  out.noisy = randomized != 0 && cfg->noise_std > 0.f;     // (noise_std is not None) and randomized, model_utils.py:329
+  out.seed = seed;
   return launch_uniform_jobs(seed, jobs, nj, s);
 }
 
@@ -261,6 +264,7 @@ static int forward_coarse(const PxoCfg* cfg, TrainWs& t, const float* pk0, const
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, dr.t_rand, t.c.z, t.c.pts, s));
   PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s));
+  if (dr.noisy) PXO_TRY(launch_add_noise(t.c.raw_sigma, B * Nc, cfg->noise_std, nullptr, dr.seed, 3, s));   // models.py:258-264
   if (pixels)
     return launch_shade_composite_train(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, pixels, B, Nc, nullptr,
                                         Nf > 0 ? t.c.weights : nullptr, t.c.ray_sse, t.c.d_raw_rgb, t.c.d_raw_sigma,
@@ -275,6 +279,7 @@ static int forward_fine(const PxoCfg* cfg, TrainWs& t, const float* pk1, const f
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, dr.u, t.f.z, t.f.pts, s));
   PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
+  if (dr.noisy) PXO_TRY(launch_add_noise(t.f.raw_sigma, B * (Nc + Nf), cfg->noise_std, nullptr, dr.seed, 4, s));   // :318-324
   if (pixels)
     return launch_shade_composite_train(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, pixels, B, Nc + Nf, nullptr,
                                         nullptr, t.f.ray_sse, t.f.d_raw_rgb, t.f.d_raw_sigma, t.n_sp, t.sp_exp, s);
@@ -421,6 +426,13 @@ int pxo_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi
   if (n == 0) return PXO_OK;
   PXO_REQUIRE(n >= 0 && out, "pxo_uniform: bad arguments");
   return launch_uniform(seed, stream_id, n, lo, hi, out, (hipStream_t)stream);
+}
+
+int pxo_add_gaussian_noise(float* raw, int64_t n, float noise_std, const float* noise, uint64_t seed, uint64_t stream_id,
+                           void* stream) {
+  if (n == 0) return PXO_OK;
+  PXO_REQUIRE(n >= 0 && raw && noise_std >= 0.f, "pxo_add_gaussian_noise: bad arguments");
+  return launch_add_noise(raw, n, noise_std, noise, seed, stream_id, (hipStream_t)stream);
 }
 
 int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, void* stream) {

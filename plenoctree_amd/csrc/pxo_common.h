@@ -180,6 +180,7 @@ int launch_mean_samples(const float* raw_rgb, const float* raw_sigma, int64_t n_
                         hipStream_t s);
 int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out,
                    hipStream_t s);
+int launch_add_noise(float* raw, int64_t n, float noise_std, const float* noise, uint64_t seed, uint64_t stream_id, hipStream_t s);
 int launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, int64_t step,
                 float grad_scale, hipStream_t s);
 // training form of the compositing: forward + pixel loss + reverse in one launch (see render_kernels.hip); serves the

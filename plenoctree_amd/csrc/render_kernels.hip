@@ -650,6 +650,49 @@ int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipSt
   return check_launch("uniform");
 }
 
+// add_gaussian_noise (nerf_sh/nerf/model_utils.py:317-332): raw += noise_std * N(0,1).  Injected draws, or Box-Muller on the
+// Philox block of the element's quad (layout in include/plenoctree_hip.h).
+__global__ void add_noise_kernel(float* __restrict__ raw, int64_t n, float noise_std, const float* __restrict__ noise,
+                                 uint64_t seed, uint64_t stream_id) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q * 4 >= n) return;
+  float z[4];
+  if (noise) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = q * 4 + i < n ? noise[q * 4 + i] : 0.0f;
+  } else {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = (float)((c[2 * h] >> 8) + 1u) * (1.0f / 16777216.0f);      // (0, 1]
+      const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);         // [0, 1)
+      const float r = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincospif(2.0f * u2, &sn, &cs);
+      z[2 * h] = r * cs;
+      z[2 * h + 1] = r * sn;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t idx = q * 4 + i;
+    if (idx < n) raw[idx] = raw[idx] + noise_std * z[i];
+  }
+}
+
+int launch_add_noise(float* raw, int64_t n, float noise_std, const float* noise, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+  if (n == 0) return PXO_OK;
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, raw, n, noise_std, noise, seed, stream_id);
+  return check_launch("add_gaussian_noise");
+}
+
 int launch_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float lo, float hi, float* out, hipStream_t s) {
   const UniformJob job{stream_id, n, lo, hi, out};
   return launch_uniform_jobs(seed, &job, 1, s);

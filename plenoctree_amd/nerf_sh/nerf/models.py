@@ -103,7 +103,8 @@ def make_cfg(args):
                         sparsity_npoints=args.sparsity_npoints, near_=args.near, far_=args.far,
                         sparsity_weight=args.sparsity_weight, sparsity_length=args.sparsity_length,
                         sparsity_radius=args.sparsity_radius, weight_decay_mult=args.weight_decay_mult,
-                        mlp_precision=1 if getattr(args, "mlp_precision", "f32") == "bf16x3" else 0)
+                        mlp_precision=1 if getattr(args, "mlp_precision", "f32") == "bf16x3" else 0,
+                        noise_std=0.0 if getattr(args, "noise_std", None) is None else args.noise_std)
 
 
 def construct_nerf(args, device, seed=None):

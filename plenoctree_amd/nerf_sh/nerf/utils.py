@@ -136,8 +136,8 @@ def check_supported(args):
         bad.append("net_depth/net_width/skip_layer != 8/256/4")
     if (args.min_deg_point, args.max_deg_point) != (0, 10):
         bad.append("min/max_deg_point != 0/10")
-    if args.noise_std is not None:
-        bad.append("noise_std")
+    if args.noise_std is not None and args.noise_std < 0:
+        bad.append("noise_std < 0")
     if getattr(args, "render_path", False) or getattr(args, "spherify", False):
         bad.append("render_path / spherify (LLFF scenes)")
     if args.legacy_posenc_order:

@@ -25,8 +25,18 @@ def main(argv=None):
     if args.mlp_precision != "f32":
         raise ValueError("--mlp_precision bf16x3 is an inference option (eval / gen_video / extraction); training runs in float32")
     h0 = comm.rank == 0
+    render_dir = os.path.join(args.train_dir, "render")
+    timings_file = None
     if h0:
-        os.makedirs(args.train_dir, exist_ok=True)
+        os.makedirs(render_dir, exist_ok=True)                        # train.py:133-135
+        timings_file = open(os.path.join(args.train_dir, "timings.txt"), "a")   # train.py:138-143
+
+    def write_ts_now(step):
+        if timings_file is not None:
+            from datetime import datetime
+            timings_file.write(f"{step} {datetime.now().isoformat()}\n")
+            timings_file.flush()
+    write_ts_now(0)
 
     per_rank = args.batch_size // comm.world
     dataset = datasets.get_dataset("train", args, device, batch_size=per_rank)
@@ -41,7 +51,7 @@ def main(argv=None):
 
     reducer = dist.GradReducer(comm, device)
     t_loop_start = time.time()
-    stats_trace = []
+    stats_trace, loss_trace = [], []
     reset_timer = True
     for step in range(init_step, args.max_steps + 1):
         if reset_timer:
@@ -56,13 +66,16 @@ def main(argv=None):
         if step % args.print_every == 0:                            # train.py:208-236
             torch.cuda.synchronize()
             s = utils.Stats(*state.stats.cpu().tolist())
+            # the reference averages the loss of every step since the last print (stats_trace, train.py:199-200,216-218);
+            # reading the device every step would serialise host and GPU, so the average here is over the printed steps
+            loss_trace.append(s.loss)
             steps_per_sec = args.print_every / (time.time() - t_loop_start)
             reset_timer = True
             rays_per_sec = args.batch_size * steps_per_sec          # train.py:224
             if h0:
                 precision = int(np.ceil(np.log10(args.max_steps))) + 1
                 print(("{:" + "{:d}".format(precision) + "d}").format(step) + f"/{args.max_steps:d}: "
-                      + f"i_loss={s.loss:0.4f}, avg_loss={s.loss:0.4f}, weight_l2={s.weight_l2:0.2e}, lr={lr:0.2e}, "
+                      + f"i_loss={s.loss:0.4f}, avg_loss={float(np.mean(loss_trace[-8:])):0.4f}, weight_l2={s.weight_l2:0.2e}, lr={lr:0.2e}, "
                       + f"{rays_per_sec:0.0f} rays/sec", flush=True)
                 stats_trace.append((step, s.loss, s.psnr, rays_per_sec))
         if step % args.save_every == 0 and h0:                      # train.py:237-242
@@ -74,13 +87,22 @@ def main(argv=None):
                 lambda r: model.apply(state, r, args.randomized, seed=step), ex["rays"], chunk=args.chunk,
                 world_size=comm.world, rank=comm.rank, gather=comm.all_gather_cat)
             torch.cuda.synchronize()
-            if h0:
+            if h0:                                                   # train.py:262-296
+                write_ts_now(step)
                 psnr = utils.compute_psnr(((rgb - ex["pixels"]) ** 2).mean().item())
+                ssim = float(utils.compute_ssim(rgb.clamp(0.0, 1.0), ex["pixels"], max_val=1.0))
                 n = ex["pixels"].shape[0] * ex["pixels"].shape[1]
-                print(f"Eval {step}: {time.time() - t0:0.3f}s., {n / (time.time() - t0):0.0f} rays/sec, PSNR {psnr:.4f}",
-                      flush=True)
+                print(f"Eval {step}: {time.time() - t0:0.3f}s., {n / (time.time() - t0):0.0f} rays/sec, PSNR {psnr:.4f}, "
+                      f"SSIM {ssim:.4f}", flush=True)
+                # [target | prediction | disparity | accumulation] side by side, render/<step>.png (train.py:283-290)
+                vis = torch.cat([ex["pixels"], rgb, disp.expand(-1, -1, 3), acc.expand(-1, -1, 3)], dim=1)
+                out_path = os.path.join(render_dir, "{:010}.png".format(step))
+                utils.save_img(vis, out_path)
+                print(" Rendering saved to ", out_path, flush=True)
     if args.max_steps % args.save_every != 0 and h0:                # train.py:306-310
         checkpoints.save_checkpoint(args.train_dir, state, int(args.max_steps), keep=200)
+    if timings_file is not None:
+        timings_file.close()
     comm.barrier()
     comm.shutdown()
     return stats_trace

@@ -190,6 +190,14 @@ def sample_pdf(z_coarse, w_coarse, origins, directions, num_fine, u=None):
     return z, pts
 
 
+def add_gaussian_noise(raw, noise_std, noise=None, seed=0, stream_id=0):
+    """model_utils.add_gaussian_noise in place: raw += noise_std * N(0,1) (`noise`: injected draws, else Philox)."""
+    _require_gpu()
+    check(_lib.load().pxo_add_gaussian_noise(_f(raw), raw.numel(), float(noise_std), _f(noise), seed, stream_id, _stream()),
+          "pxo_add_gaussian_noise")
+    return raw
+
+
 def uniform(seed, stream_id, n, lo=0.0, hi=1.0, device=None):
     _require_gpu()
     lib = _lib.load()

@@ -14,7 +14,7 @@ sample_along_rays, volumetric_rendering, piecewise_constant_pdf, sample_pdf) and
 So the stored gradient is reverse-mode AD through the reference's function bodies, not through our restatement.
 Run in the authoring container only (needs /root/reference):
     python tests/golden/make_golden_grad.py
-Writes tests/golden/train_grad.npz.  Weights: those of eval_points_sh16.npz (reference torch twin, seed 20200823)
+Writes tests/golden/train_grad.npz and tests/golden/nerf_model_noise.npz (NerfModel.__call__ with noise_std = 0.3: F4).  Weights: those of eval_points_sh16.npz (reference torch twin, seed 20200823)
 with the sigma-head bias of both MLPs raised by 0.5 so that every ray sees density (the loss then reaches every
 parameter and the inverse-CDF sampling has no empty bins).
 """
@@ -188,10 +188,10 @@ class Shim:
         self.train = _load("ref_nerf_sh_train_torch", os.path.join(REF, "nerf_sh/train.py"))
         self.linen = linen
 
-    def model(self, sh_deg=3):
+    def model(self, sh_deg=3, noise_std=None):
         return self.models.NerfModel(
             num_coarse_samples=64, num_fine_samples=128, use_viewdirs=False, sh_deg=sh_deg, sg_dim=-1, near=2.0, far=6.0,
-            noise_std=None, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
+            noise_std=noise_std, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
             net_activation=self.linen.relu, skip_layer=4, num_rgb_channels=3 * (sh_deg + 1) ** 2, num_sigma_channels=1,
             white_bkgd=True, min_deg_point=0, max_deg_point=10, deg_view=4, lindisp=False,
             rgb_activation=self.linen.sigmoid, sigma_activation=self.linen.relu, legacy_posenc_order=False)
@@ -226,6 +226,32 @@ class Shim:
         _, stats, _ = self.train.train_step(ModelApply(), keys, state, {"rays": rays, "pixels": T(batch_np["pixels"])}, 5e-4)
         grad = [[(k.detach().numpy(), b.detach().numpy()) for k, b in mlp] for mlp in got["grad"]]
         return {k: float(getattr(stats, k)) for k in self.Stats._fields}, grad
+
+
+def noise_fixture(weights, rng):
+    """NerfModel.__call__ with noise_std = 0.3 (models.py:258-264,318-324 -> model_utils.add_gaussian_noise :317-332):
+    the two normal draws are injected through the keys, like the uniforms."""
+    f32 = np.float32
+    sh = Shim(torch.float32)
+    model = sh.model(noise_std=0.3)
+    B = 5
+    cam = rng.normal(size=(B, 3)); cam = (4.0 * cam / np.linalg.norm(cam, axis=-1, keepdims=True)).astype(f32)
+    d = (-cam / 4.0 + 0.08 * rng.normal(size=(B, 3))).astype(f32)
+    v = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(f32)
+    t_rand, u = rng.uniform(size=(B, 64)).astype(f32), rng.uniform(size=(B, 128)).astype(f32)
+    noise_c, noise_f = rng.normal(size=(B, 64)).astype(f32), rng.normal(size=(B, 192)).astype(f32)
+    out = dict(origins=cam, directions=d, viewdirs=v, t_rand=t_rand, u=u, noise_c=noise_c, noise_f=noise_f, noise_std=0.3)
+    leaves = [[(torch.tensor(k), torch.tensor(b)) for k, b in mlp] for mlp in weights]
+    with torch.no_grad():
+        for randomized in (False, True):
+            sh.weight_queue[:] = [wb for mlp in leaves for wb in mlp]
+            ret = model([t_rand, noise_c], [u, noise_f], sh.Rays(*[sh.T(x) for x in (cam, d, v)]), randomized)
+            assert not sh.weight_queue
+            for lvl, (rgb_, disp_, acc_) in zip(("coarse", "fine"), ret):
+                out[f"rgb_{lvl}_r{int(randomized)}"] = rgb_.numpy().astype(f32)
+                out[f"acc_{lvl}_r{int(randomized)}"] = acc_.numpy().astype(f32)
+    np.savez_compressed(os.path.join(HERE, "nerf_model_noise.npz"), **out)
+    print("wrote", os.path.join(HERE, "nerf_model_noise.npz"))
 
 
 def flat_grad(grad):
@@ -270,6 +296,9 @@ def main():
         print(f"  MLP_{mi}: reference-f32 vs reference-f64 rel L2 {float(out[f'grad_f32_vs_f64_rel_l2_mlp{mi}']):.3e}")
     np.savez_compressed(os.path.join(HERE, "train_grad.npz"), **out)
     print("wrote", os.path.join(HERE, "train_grad.npz"))
+    plain = [[(gw[f"MLP_{mi}.Dense_{li}.kernel"].copy(), gw[f"MLP_{mi}.Dense_{li}.bias"].copy()) for li in range(10)]
+             for mi in range(2)]
+    noise_fixture(plain, np.random.default_rng(424242))
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@ reference's own modules (nerf_sh/nerf/model_utils.py, models.py, sh.py, train.py
 function bodies.  One test per SURVEY 8(a) row:
 
   F1  sample_along_rays + cast_rays   model_utils.py:97-142    pxo_sample_along_rays      model_utils.npz
+  F4  add_gaussian_noise              model_utils.py:317-332   pxo_add_gaussian_noise     nerf_model_noise.npz
   F5  eval_sh                         sh.py:54-109             pxo_shade_composite_fwd    eval_sh.npz
   F6  sigmoid / relu                  models.py:280-281        pxo_shade_composite_fwd    eval_sh.npz / model_utils.npz
   F7  volumetric_rendering            model_utils.py:176-222   pxo_shade_composite_fwd    model_utils.npz
@@ -168,6 +169,60 @@ def test_render_fwd_against_reference_nerf_model_call(golden_dir):
             _allclose(f"rgb {lvl} r{r}", rgb, g[f"rgb_{lvl}_r{r}"], 0, 2e-5)
             _allclose(f"acc {lvl} r{r}", acc, g[f"acc_{lvl}_r{r}"], 0, 2e-5)
             _allclose(f"disp {lvl} r{r}", disp, g[f"disp_{lvl}_r{r}"], 2e-3, 1e-6)
+
+
+def test_gaussian_noise_against_reference(golden_dir):
+    """F4.  nerf_model_noise.npz = the reference's NerfModel.__call__ with noise_std = 0.3 and the two normal draws injected.
+    The whole-path entry points draw their normals from Philox, so the injected form is run through the SAME kernels in the
+    whole path's order (pxo_sample_along_rays -> pxo_mlp_fwd -> pxo_add_gaussian_noise -> pxo_shade_composite_fwd ->
+    pxo_sample_pdf -> ...).  rgb / acc atol 2e-5, both levels.  Then the Philox normals: Box-Muller of the pinned uniform
+    words (host restatement, atol 2e-6 on values up to ~5), mean / variance of 2^20 draws, and the whole path with
+    PxoCfg.noise_std > 0: deterministic per seed, different from the noise-free render, untouched when randomized = 0."""
+    ops = _ops(); dev = _gpu()
+    from _helpers import philox4x32_10
+    g = np.load(os.path.join(golden_dir, "nerf_model_noise.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    std = float(g["noise_std"])
+    pcfg = ops.make_cfg(noise_std=std)
+    flat = _params_flat(gw).to(dev)
+    n = flat.numel() // 2
+    pk = [ops.pack_weights(pcfg, flat[i * n:(i + 1) * n].contiguous(), need_bwd=False)[0] for i in range(2)]
+    o, d, v = [torch.tensor(g[k], device=dev) for k in ("origins", "directions", "viewdirs")]
+    t = lambda k: torch.tensor(g[k], device=dev)
+    z_c, pts = ops.sample_along_rays(o, d, 64, 2.0, 6.0, t("t_rand"))
+    raw_rgb, raw_sigma = ops.mlp_fwd(pcfg, pk[0], pts)
+    ops.add_gaussian_noise(raw_sigma, std, noise=t("noise_c").reshape(-1).contiguous())
+    rgb_c, _, acc_c, w = ops.shade_composite_fwd(pcfg, raw_rgb, raw_sigma, z_c, d, v)
+    z_f, pts_f = ops.sample_pdf(z_c, w, o, d, 128, t("u"))
+    raw_rgb, raw_sigma = ops.mlp_fwd(pcfg, pk[1], pts_f)
+    ops.add_gaussian_noise(raw_sigma, std, noise=t("noise_f").reshape(-1).contiguous())
+    rgb_f, _, acc_f, _ = ops.shade_composite_fwd(pcfg, raw_rgb, raw_sigma, z_f, d, v)
+    for name, got in (("rgb_coarse_r1", rgb_c), ("acc_coarse_r1", acc_c), ("rgb_fine_r1", rgb_f), ("acc_fine_r1", acc_f)):
+        _allclose(name, got, g[name], 0, 2e-5)
+    # Philox normals: element 4q + {0,1} from words (0,1) of block q, 4q + {2,3} from words (2,3)
+    seed, sid, cnt = 0x1234567, 5, 37
+    z = ops.add_gaussian_noise(torch.zeros(cnt, device=dev), 1.0, seed=seed, stream_id=sid).cpu().numpy()
+    want = np.empty(cnt)
+    for q in range((cnt + 3) // 4):
+        wds = philox4x32_10((q, 0, sid, 0), (seed, 0))
+        for h in range(2):
+            u1 = ((wds[2 * h] >> 8) + 1) / 16777216.0
+            u2 = (wds[2 * h + 1] >> 8) / 16777216.0
+            r = np.sqrt(-2.0 * np.log(u1))
+            for k, val in enumerate((r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2))):
+                if 4 * q + 2 * h + k < cnt:
+                    want[4 * q + 2 * h + k] = val
+    np.testing.assert_allclose(z, want, rtol=0, atol=2e-6)
+    big = ops.add_gaussian_noise(torch.zeros(1 << 20, device=dev), 2.0, seed=9, stream_id=3)
+    assert abs(float(big.mean())) < 1e-2 and abs(float(big.var()) - 4.0) < 4e-2
+    # whole path
+    a = ops.render_fwd(pcfg, pk[0], pk[1], o, d, v, randomized=True, seed=11)
+    b = ops.render_fwd(pcfg, pk[0], pk[1], o, d, v, randomized=True, seed=11)
+    c = ops.render_fwd(ops.make_cfg(), pk[0], pk[1], o, d, v, randomized=True, seed=11)
+    assert torch.equal(a[1][0], b[1][0]) and float((a[1][0] - c[1][0]).abs().max()) > 1e-3
+    for r in (0,):
+        det = ops.render_fwd(pcfg, pk[0], pk[1], o, d, v, randomized=False)
+        _allclose("deterministic render ignores noise_std", det[1][0], g["rgb_fine_r0"], 0, 2e-5)
 
 
 def _train_once(ops, dev, g, gw, shift, n_sp, wd):

@@ -172,6 +172,20 @@ def test_area_resize_full_size_is_block_mean_and_fast():
     assert odd.shape == (300, 500, 4) and abs(float(odd.mean()) - float(img.mean())) < 1e-5
 
 
+def test_noise_std_flag_reaches_the_cfg():
+    """--noise_std (nerf_sh/nerf/utils.py:137-140; None in every preset) is accepted and becomes PxoCfg.noise_std; None = 0."""
+    from plenoctree_amd.nerf_sh.nerf import models
+    a = _args(["--config", "blender", "--train_dir", "x", "--noise_std", "0.25"])
+    utils.update_flags(a)
+    utils.check_supported(a)
+    assert models.make_cfg(a).noise_std == pytest.approx(0.25)
+    a.noise_std = None
+    assert models.make_cfg(a).noise_std == 0.0
+    a.noise_std = -1.0
+    with pytest.raises(NotImplementedError):
+        utils.check_supported(a)
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run, one rank per GPU
     (rendezvous on 127.0.0.1); with too few devices it says so instead of asking for a wrapper."""

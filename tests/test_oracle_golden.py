@@ -201,6 +201,27 @@ def test_loss_matches_the_reference_train_step(golden_dir):
     assert float(total) == pytest.approx(float(g["total"]), rel=2e-5)
 
 
+def test_render_with_gaussian_noise_matches_the_reference(golden_dir):
+    """tests/golden/nerf_model_noise.npz: the reference's NerfModel.__call__ with noise_std = 0.3 (add_gaussian_noise,
+    model_utils.py:317-332, on raw sigma between the MLP and the relu, models.py:258-264,318-324), the normal draws
+    injected through the keys.  randomized=False must ignore noise_std."""
+    g = np.load(os.path.join(golden_dir, "nerf_model_noise.npz"))
+    gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
+    cfg = O.Cfg(noise_std=float(g["noise_std"]))
+    params = _params_from_npz(gw, cfg)
+    rays = O.Rays(*[torch.tensor(g[k]) for k in ("origins", "directions", "viewdirs")])
+    t = lambda k: torch.tensor(g[k])
+    with torch.no_grad():
+        noisy = O.render(params, rays, cfg, t("t_rand"), t("u"), noise_c=t("noise_c"), noise_f=t("noise_f"))
+        det = O.render(params, rays, cfg)
+        plain = O.render(params, rays, O.Cfg(), t("t_rand"), t("u"))
+    for r, out in ((1, noisy), (0, det)):
+        for lvl, (rgb, disp, acc) in zip(("coarse", "fine"), out):
+            np.testing.assert_allclose(rgb.numpy(), g[f"rgb_{lvl}_r{r}"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(acc.numpy(), g[f"acc_{lvl}_r{r}"], rtol=0, atol=2e-5)
+    assert float((noisy[1][0] - plain[1][0]).abs().max()) > 1e-2          # the noise is not a no-op
+
+
 def _train_grad_inputs(g, gw, dtype):
     """Inputs of tests/golden/train_grad.npz in `dtype` (weights of eval_points_sh16.npz, sigma-head biases + shift)."""
     cfg = O.Cfg(sparsity_npoints=int(g["sparsity_npoints"]), weight_decay_mult=float(g["weight_decay_mult"]))

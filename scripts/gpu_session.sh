@@ -20,6 +20,7 @@ R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 HEAD_ARGS="--no-cpu-baseline --no-extras"
+PROF_HEAD_ARGS="$HEAD_ARGS --no-kernel-events"      # under rocprofv3 the HIP-event brackets are only extra barrier packets
 nproc > gpurun_out/device.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/device.txt
 
 brief() {   # one line per bench JSON: rays/s, ms/step, kernels
@@ -62,7 +63,7 @@ for stage in ${STAGES:-tests bench}; do
     echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
   prof)
     cd /tmp
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 $HEAD_ARGS ${PROF_ARGS:-} > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 $PROF_HEAD_ARGS ${PROF_ARGS:-} > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
     echo "rocprof exit $?"; cd "$R"
     f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f"
     f=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/gap_analysis.py "$f" | tee gpurun_out/gaps.txt
@@ -71,7 +72,7 @@ for stage in ${STAGES:-tests bench}; do
     cd /tmp; i=0
     for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
       i=$((i+1))
-      timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 $HEAD_ARGS > /dev/null 2> "$R/gpurun_out/pmc$i.err"
+      timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 $PROF_HEAD_ARGS > /dev/null 2> "$R/gpurun_out/pmc$i.err"
       echo "pmc pass $i exit $?"
     done
     cd "$R"; find gpurun_out -name "*.csv" -size +30M -delete ;;
@@ -80,7 +81,7 @@ for stage in ${STAGES:-tests bench}; do
       timeout 300 python bench.py --batch $B --steps 40 --warmup 5 $HEAD_ARGS ${TL_ARGS:-} > gpurun_out/bench_b$B.json 2> gpurun_out/bench_b$B.err
       echo "bench B=$B exit $?"; brief gpurun_out/bench_b$B.json timeline $B
       cd /tmp
-      timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/trace_b$B" -o t -- python "$R/bench.py" --batch $B --steps 12 --warmup 3 $HEAD_ARGS ${TL_ARGS:-} > /dev/null 2> "$R/gpurun_out/trace_b$B.err"
+      timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/trace_b$B" -o t -- python "$R/bench.py" --batch $B --steps 12 --warmup 3 $PROF_HEAD_ARGS ${TL_ARGS:-} > /dev/null 2> "$R/gpurun_out/trace_b$B.err"
       echo "rocprof B=$B exit $?"; cd "$R"
       f=$(find gpurun_out/trace_b$B -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/step_timeline.py "$f" 4 > gpurun_out/timeline_b$B.txt && head -${TL_HEAD:-50} gpurun_out/timeline_b$B.txt

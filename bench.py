@@ -101,6 +101,7 @@ def flags_for(a, preset, batch, **over):
     args.batch_size = batch
     args.factor = a.image_factor          # 0: 800 x 800
     args.train_dir = "/tmp/pxo_bench"
+    args.skip_zero_rows = False           # every throughput record runs the DENSE reverse pass (the reference's value_and_grad)
     if a.sparsity_npoints is not None:
         args.sparsity_npoints = a.sparsity_npoints
     for k, v in over.items():
@@ -339,7 +340,34 @@ def run_converge(job, a):
         psnrs.append(utils.compute_psnr(((rgb - ex["pixels"]) ** 2).mean().item()))
     job.sync()
     t_render = job.max_over_ranks(time.perf_counter() - t1)
-    return {"eval_psnr": sum(psnrs) / len(psnrs), "eval_psnr_per_view": psnrs, "views": n_views,
+    # At this trained state: the same steps with the dense reverse pass and with PxoCfg.skip_zero_rows (sample rows whose
+    # upstream gradient is exactly zero -- empty space, occluded samples, background rays -- left out of backward(data) and
+    # the weight-gradient GEMMs in 16-row chunks; bit-identical gradients, tests/test_gpu_parity.py).  Not the headline:
+    # the saving is a property of the scene, here 78 % background pixels.
+    from plenoctree_amd import ops
+
+    def timed_steps(first, n):
+        job.sync()
+        t = time.perf_counter()
+        for s_ in range(first, first + n):
+            tr["one_step"](s_)
+        job.sync()
+        return tr["per_gpu"] * job.world * n / job.max_over_ranks(time.perf_counter() - t)
+
+    k = 50 if job.cuda else 1
+    s0 = a.converge_steps
+    dense_rps = timed_steps(s0, k)
+    sparse = {"dense_rays_per_s": dense_rps}
+    if job.cuda:
+        model.cfg.skip_zero_rows = 1
+        timed_steps(s0 + k, 3)
+        sparse["skip_zero_rows_rays_per_s"] = timed_steps(s0 + k + 3, k)
+        live, total = ops.train_backward_work(model.cfg, tr["per_gpu"], state._ws)
+        model.cfg.skip_zero_rows = 0
+        sparse.update(live_chunk_fraction=live / max(total, 1), steps_each=k, after_steps=s0,
+                      note="opt-in PxoCfg.skip_zero_rows: rows with an exactly zero upstream gradient skipped in 16-row chunks; "
+                           "gradients bit-identical to the dense pass; scene-dependent, not part of any other record")
+    return {"eval_psnr": sum(psnrs) / len(psnrs), "sparse_backward": sparse, "eval_psnr_per_view": psnrs, "views": n_views,
             "view_size": [test.h, test.w], "train_steps": a.converge_steps, "rays_per_step": tr["per_gpu"] * job.world,
             "train_s": t_train, "train_rays_per_s": tr["per_gpu"] * job.world * a.converge_steps / t_train,
             "train_psnr_last_batch": tr["stats"]["psnr"], "render_s": t_render,

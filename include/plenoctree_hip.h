@@ -64,6 +64,12 @@ typedef struct PxoCfg {
   int32_t mlp_precision;       /* PXO_MLP_F32 (0, default) or PXO_MLP_BF16X3: INFERENCE-ONLY opt-in, see below */
   float noise_std;             /* 0 = the reference's None (every preset); > 0: add_gaussian_noise on raw sigma of the ray
                                   samples when randomized (nerf_sh/nerf/models.py:258-264,318-324) */
+  int32_t skip_zero_rows;      /* pxo_train_fwd_bwd only.  1: sample rows whose upstream gradient (d loss / d raw_rgb, d raw_sigma) is
+                                  EXACTLY zero -- empty space (relu(sigma) = 0, hence weight 0), samples behind an opaque surface,
+                                  whole background rays -- are left out of the reverse pass in 16-row chunks (128-row tiles in the
+                                  backward(data) kernel).  The gradients are bit-identical (only exact zeros leave the sums); the
+                                  time saved depends on the scene, so bench.py's throughput records run with 0 = dense, like the
+                                  reference's jax.value_and_grad (nerf_sh/train.py:116) */
 } PxoCfg;
 
 /* PxoCfg.mlp_precision.  PXO_MLP_F32: exact float32 MFMA everywhere (the reference's precision; training and every
@@ -263,6 +269,12 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
                                const float* t_rand, const float* u, const float* sp_points, uint64_t seed,
                                float* grads, float* stats, void* ws, size_t ws_bytes, void* grads0_ready,
                                void* stream);
+
+/* How much of the last pxo_train_fwd_bwd call's reverse pass was live: 16-row chunks with a non-zero upstream gradient
+ * out of all chunks of both levels (with cfg->skip_zero_rows = 0 both numbers are the total).  Reads the flags the call
+ * left in `ws`; synchronises `stream`.  Reporting only (bench.py's `converge` record, tests). */
+int pxo_train_backward_work(const PxoCfg* cfg, int64_t B, void* ws, size_t ws_bytes, int64_t* live_chunks,
+                            int64_t* total_chunks, void* stream);
 
 /* Plain event handles for the call above (hipEventDisableTiming), so that a host runtime whose own event objects are
  * lazily created or private (torch.cuda.Event) can still order its collective stream behind the bucket:

@@ -41,6 +41,7 @@ class PxoCfg(Structure):
         ("weight_decay_mult", c_float),
         ("mlp_precision", c_int32),
         ("noise_std", c_float),
+        ("skip_zero_rows", c_int32),
     ]
 
 
@@ -110,6 +111,7 @@ SIGNATURES = {
                                   P, c_size_t, P]),
     "pxo_train_fwd_bwd_bucketed": (c_int, [CFG, P, P, P, P, P, P, P, P, P, c_int64, c_int, P, P, P, c_uint64, P, P,
                                            P, c_size_t, P, P]),
+    "pxo_train_backward_work": (c_int, [CFG, c_int64, P, c_size_t, POINTER(c_int64), POINTER(c_int64), P]),
     "pxo_event_create": (c_int, [POINTER(c_void_p)]),
     "pxo_event_destroy": (c_int, [P]),
     "pxo_stream_wait_event": (c_int, [P, P]),
@@ -186,7 +188,7 @@ def make_cfg(**kw):
     vals = dict(num_coarse_samples=64, num_fine_samples=128, sh_deg=3, min_deg_point=0, max_deg_point=10,
                 white_bkgd=1, lindisp=0, sparsity_npoints=10000, near_=2.0, far_=6.0,
                 sparsity_weight=1e-3, sparsity_length=0.05, sparsity_radius=1.5, weight_decay_mult=0.0,
-                mlp_precision=0, noise_std=0.0)
+                mlp_precision=0, noise_std=0.0, skip_zero_rows=0)
     for k, v in kw.items():
         if k not in vals:
             raise ValueError(f"unknown PxoCfg field {k}")

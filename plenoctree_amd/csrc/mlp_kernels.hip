@@ -721,14 +721,18 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
                                          const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
                                          const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask,
                                          int64_t M, int deg, int64_t row0, int64_t slot, float* __restrict__ dz,
+                                         int* __restrict__ nz, uint8_t* __restrict__ chunk_live,
                                          int tid, int lane, int wave) {
   constexpr int NH = 32 * NHB;
   constexpr int kRows = 32 * RBN;
   constexpr int kWordsUsed = RBN * kCB * 16 / 32;
+  constexpr int kChunks = kRows / kLiveRows;
   const int C = rgb_channels(deg);
   const ARows arow = make_arows(lds, lane);
   const WImage wimg = make_wimage(pkb, bwd_image_floats(deg), lane);
   lds_barrier();   // previous tile's stores out of LDS are done
+  if (chunk_live && tid < kChunks) nz[tid] = 0;
+  if (chunk_live) lds_barrier();
   // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
   for (int idx = tid; idx < kRows * NH; idx += kMlpThreads) {
     const int row = idx / NH, col = idx - row * NH;
@@ -739,8 +743,21 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
       else if (col == C) v = d_raw_sigma[grow];
     }
     lds[row * kLDA + col] = v;
+    if (chunk_live && v != 0.f) nz[row / kLiveRows] = 1;          // same value from every writer
   }
   lds_barrier();
+  if (chunk_live) {
+    // Rows whose upstream gradient (d_raw_rgb, d_raw_sigma) is exactly zero -- samples in empty space (relu(sigma) = 0
+    // and weight 0), samples behind an opaque surface, every sample of a background ray -- have dz_l = 0 in every layer
+    // and add exactly 0 to every weight and bias gradient.  Per 16-row chunk a flag says whether any row is live: the
+    // weight-gradient kernels skip dead chunks (they then never read this tile's dz), and a tile without a live chunk is
+    // skipped here altogether.  Results are bit-identical to the dense pass (sums lose only exact zeros).
+    int any = 0;
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) any |= nz[c];
+    if (tid < kChunks) chunk_live[row0 / kLiveRows + tid] = (uint8_t)nz[tid];
+    if (!any) return;
+  }
   if (tid < NH) {  // head bias gradient
     float sum = 0.f;
 #pragma unroll 8
@@ -801,19 +818,21 @@ template <int NHB>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg, TileSched ts,
-    float* __restrict__ dz, float* __restrict__ dbias_partial) {
+    float* __restrict__ dz, float* __restrict__ dbias_partial, uint8_t* __restrict__ chunk_live) {
   // activation-gradient tile + this workgroup's bias-gradient accumulators [9][256] (each element is
   // read-modify-written by one fixed thread; kept in LDS so the epilogue never waits on memory)
-  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + 9 * kW];
+  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + 9 * kW + kTM / kLiveRows];
   float* __restrict__ my_db = lds + kTM * kLDA;
+  int* __restrict__ nz = reinterpret_cast<int*>(lds + kTM * kLDA + 9 * kW);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < 9 * kW; i += kMlpThreads) my_db[i] = 0.f;
   for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)
-    bwd_tile<NHB, kRB>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, tile * kTM, tile, dz, tid, lane, wave);
+    bwd_tile<NHB, kRB>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, tile * kTM, tile, dz, nz, chunk_live, tid, lane,
+                       wave);
   for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
     bwd_tile<NHB, kRB / 2>(lds, my_db, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, ts.half_row0 + h * (kTM / 2),
-                           ts.n_full + h, dz, tid, lane, wave);
+                           ts.n_full + h, dz, nz, chunk_live, tid, lane, wave);
   lds_barrier();
   // one partial per workgroup: [wg][9][256]
   float* out = dbias_partial + (int64_t)blockIdx.x * 9 * kW;
@@ -824,7 +843,7 @@ int mlp_bwd_partials(int64_t M) { return (int)mlp_grid(M); }
 
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
-                        float* dbias_partial, hipStream_t s) {
+                        float* dbias_partial, uint8_t* chunk_live, hipStream_t s) {
   if (M == 0) return PXO_OK;
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
@@ -832,15 +851,15 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
   switch (head_blocks(cfg->sh_deg)) {
     case 1:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live);
       break;
     case 2:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<2>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live);
       break;
     default:
       hipLaunchKernelGGL((mlp_bwd_data_kernel<3>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial);
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live);
       break;
   }
   return check_launch("mlp_bwd_data");

@@ -56,6 +56,7 @@ int validate_cfg(const PxoCfg* cfg) {
   PXO_REQUIRE(cfg->mlp_precision == PXO_MLP_F32 || cfg->mlp_precision == PXO_MLP_BF16X3, "mlp_precision %d unknown",
               cfg->mlp_precision);
   PXO_REQUIRE(cfg->noise_std >= 0.f, "noise_std %g < 0 (0 = None)", (double)cfg->noise_std);
+  PXO_REQUIRE(cfg->skip_zero_rows == 0 || cfg->skip_zero_rows == 1, "skip_zero_rows %d is not 0 / 1", cfg->skip_zero_rows);
   return PXO_OK;
 }
 
@@ -153,6 +154,7 @@ struct PassBuffers {      // one MLP pass (coarse or fine)
   float *z, *pts, *raw_rgb, *raw_sigma, *acts, *enc, *comp_rgb, *disp, *acc, *weights;
   uint32_t* mask;
   float *ray_sse, *d_raw_rgb, *d_raw_sigma, *dz, *dbias;
+  uint8_t* live;          // one flag per kLiveRows rows: written by the backward(data) kernel, read by the wgrad kernels
 };
 
 static void carve_pass(Carver& c, PassBuffers& p, int64_t B, int S, int64_t extra_rows, int C, bool train,
@@ -178,9 +180,11 @@ static void carve_pass(Carver& c, PassBuffers& p, int64_t B, int S, int64_t extr
     p.d_raw_sigma = c.take<float>(p.M);
     p.dz = c.take<float>(p.M * kW * kDepth);
     p.dbias = c.take<float>(dbias_floats(p.M));
+    p.live = c.take<uint8_t>(live_flags(p.M));
   } else {
     p.acts = p.enc = p.ray_sse = p.d_raw_rgb = p.d_raw_sigma = p.dz = p.dbias = nullptr;
     p.mask = nullptr;
+    p.live = nullptr;
   }
 }
 
@@ -359,7 +363,7 @@ int pxo_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_
   PXO_REQUIRE(M >= 0 && packed_bwd && d_raw_rgb && d_raw_sigma && relu_mask && dz && dbias_partial,
               "pxo_mlp_bwd_data: bad arguments");
   return launch_mlp_bwd_data(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, (const uint32_t*)relu_mask, M, dz,
-                             dbias_partial, (hipStream_t)stream);
+                             dbias_partial, nullptr, (hipStream_t)stream);
 }
 
 int pxo_wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M, size_t* bytes) {
@@ -376,7 +380,7 @@ int pxo_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, 
   PXO_REQUIRE(M >= 0 && acts && enc && dz && d_raw_rgb && d_raw_sigma && dbias_partial && grads && ws,
               "pxo_mlp_bwd_weights: bad arguments");
   return launch_mlp_bwd_weights(cfg, acts, enc, dz, d_raw_rgb, d_raw_sigma, dbias_partial, M, grads, ws, ws_bytes,
-                                (hipStream_t)stream);
+                                nullptr, (hipStream_t)stream);
 }
 
 int pxo_shade_composite_fwd(const PxoCfg* cfg, const float* raw_rgb, const float* raw_sigma, const float* z_vals,
@@ -556,9 +560,12 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   // level feeds MLP_0's gradient (the fine sample positions carry no gradient, model_utils.py:286), so it is complete here
   // -- a quarter into the step -- and its all-reduce can ride under the fine level.
   PXO_TRY(forward_coarse(cfg, t, packed_fwd0, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
-  PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, s));
+  // skip_zero_rows: rows with an exactly zero upstream gradient are left out of the reverse pass (bit-identical gradients)
+  uint8_t* const live_c = cfg->skip_zero_rows ? t.c.live : nullptr;
+  uint8_t* const live_f = cfg->skip_zero_rows ? t.f.live : nullptr;
+  PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c, s));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
-                                 grads, t.wgrad_ws, t.wgrad_bytes, s));
+                                 grads, t.wgrad_ws, t.wgrad_bytes, live_c, s));
   if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads, params, n_mlp, wd_coef, s));
   if (grads0_ready && hipEventRecord((hipEvent_t)grads0_ready, s) != hipSuccess) {
     set_error("pxo_train_fwd_bwd: hipEventRecord(grads0_ready) failed");
@@ -566,9 +573,9 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   }
   if (Nf > 0) {
     PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
-    PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, s));
+    PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, live_f, s));
     PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
-                                   grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, s));
+                                   grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, live_f, s));
   } else {
     PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
   }
@@ -587,6 +594,30 @@ int pxo_train_fwd_bwd(const PxoCfg* cfg, const float* params, const float* packe
   return pxo_train_fwd_bwd_bucketed(cfg, params, packed_fwd0, packed_bwd0, packed_fwd1, packed_bwd1, origins, directions,
                                     viewdirs, pixels, B, randomized, t_rand, u, sp_points, seed, grads, stats, ws, ws_bytes,
                                     nullptr, stream);
+}
+
+int pxo_train_backward_work(const PxoCfg* cfg, int64_t B, void* ws, size_t ws_bytes, int64_t* live_chunks,
+                            int64_t* total_chunks, void* stream) {
+  PXO_TRY(validate_cfg(cfg));
+  PXO_REQUIRE(B >= 1 && ws && live_chunks && total_chunks, "pxo_train_backward_work: bad arguments");
+  TrainWs t;
+  carve_train(cfg, B, ws, true, t);
+  if (ws_bytes < t.total) { set_error("pxo_train_backward_work: workspace %zu < %zu", ws_bytes, t.total); return PXO_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nc = (t.c.M + kLiveRows - 1) / kLiveRows, nf = cfg->num_fine_samples > 0 ? (t.f.M + kLiveRows - 1) / kLiveRows : 0;
+  *total_chunks = nc + nf;
+  if (!cfg->skip_zero_rows) { *live_chunks = nc + nf; return PXO_OK; }
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(t.scalars + 96);     // 8-byte aligned tail of the scalars block
+  if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return PXO_ERR_HIP; }
+  PXO_TRY(launch_count_live(t.c.live, nc, cnt, s));
+  if (nf > 0) PXO_TRY(launch_count_live(t.f.live, nf, cnt, s));
+  unsigned long long host = 0;
+  if (hipMemcpyAsync(&host, cnt, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    set_error("pxo_train_backward_work: copy back failed");
+    return PXO_ERR_HIP;
+  }
+  *live_chunks = (int64_t)host;
+  return PXO_OK;
 }
 
 // plain handles for the bucketed form: the caller's runtime (torch) creates its events lazily and keeps them private

@@ -24,6 +24,7 @@ constexpr int kLDA = 260;                // LDS row stride (floats): 256 + one b
 constexpr int kMlpWaves = kMlpThreads / 64;
 constexpr int kMaskWords = (kTM / 32) * (8 / kMlpWaves) * 16 / 32;  // relu-mask words per thread per layer
 constexpr int kMaxMlpGrid = 1024;        // upper bound on persistent workgroups
+constexpr int kLiveRows = 16;            // rows per "live" flag of the zero-row skipping backward (= the wgrad chunk height)
 
 // ---- derived sizes -----------------------------------------------------------------
 __host__ __device__ inline int sh_dim(int deg) { return (deg + 1) * (deg + 1); }
@@ -146,14 +147,18 @@ int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* b
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
                    float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
                    hipStream_t s);
+// chunk_live (may be NULL = dense): one byte per kLiveRows rows, WRITTEN by the backward(data) kernel (1: some row of the
+// chunk has a non-zero upstream gradient) and READ by the weight-gradient kernels, which skip dead chunks
+__host__ __device__ inline int64_t live_flags(int64_t M) { return (M + kLiveRows - 1) / kLiveRows + kTM / kLiveRows; }
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
-                        float* dbias_partial, hipStream_t s);
+                        float* dbias_partial, uint8_t* chunk_live, hipStream_t s);
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
-                           size_t ws_bytes, hipStream_t s);
+                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s);
+int launch_count_live(const uint8_t* chunk_live, int64_t n, unsigned long long* out, hipStream_t s);
 int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
 // opt-in split-precision forward (mlp_x3_kernels.hip); pts == nullptr selects the dense-grid point source
 int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipStream_t s);

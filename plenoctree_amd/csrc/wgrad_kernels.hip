@@ -25,8 +25,9 @@ template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSP
 __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
     int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr,
-    int n_layers = 1, int64_t layer_stride = 0) {
+    int n_layers = 1, int64_t layer_stride = 0, const uint8_t* __restrict__ chunk_live = nullptr) {
   static_assert(WR * WC * 64 == NT, "wave grid");
+  static_assert(KCH == kLiveRows, "one live flag per staged chunk");
   static_assert(!DUAL || (NOUT == 2 * kW && NSPLIT == 1 && !HEAD), "dual source: two 256-wide arrays, no split");
   constexpr int NTILE = NOUT / NSPLIT;
   constexpr int RB = KIN / 32 / WR, CB = NTILE / 32 / WC;
@@ -201,16 +202,42 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     __syncthreads();
   };
 
+  // Zero-row skipping (chunk_live != NULL): the backward(data) kernel flagged every 16-row chunk that has a row with a
+  // non-zero upstream gradient; all other rows have dz = 0 in every layer (and may not even have been written), so their
+  // chunks add exactly nothing.  Wave 0 compacts the range's live chunks, in order, into an LDS list; the loop then walks
+  // the list instead of 0..nchunks-1 (same accumulation order over the chunks that contribute: bit-identical sums).
+  constexpr int kMaxLive = 2048;                       // longer ranges (> 32 k rows) run dense
+  __shared__ uint16_t live_list[kMaxLive];
+  __shared__ int live_count;
+  const bool sparse = chunk_live != nullptr && nchunks <= kMaxLive;
+  int n_run = nchunks;
+  if (sparse) {
+    if (wave == 0) {
+      const uint8_t* fl = chunk_live + r_begin / KCH;
+      int base = 0;
+      for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        const bool lv = c < nchunks && fl[c] != 0;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(lv);
+        if (lv) live_list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)c;
+        base += __builtin_popcountll(m);
+      }
+      if (lane == 0) live_count = base;
+    }
+    __syncthreads();
+    n_run = live_count;
+  }
+  auto chunk_at = [&](int i) { return sparse ? (int)live_list[i] : i; };
   {
     Stage st;
-    if (nchunks > 0) {
-      load_chunk(0, st);
+    if (n_run > 0) {
+      load_chunk(chunk_at(0), st);
       store_chunk(0, st);
     }
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const bool more = ch + 1 < nchunks;
-      run_chunk(ch, ch & 1, st, ch + 1, more, st, more);
+    for (int i = 0; i < n_run; ++i) {
+      const bool more = i + 1 < n_run;
+      run_chunk(i, i & 1, st, more ? chunk_at(i + 1) : 0, more, st, more);
     }
   }
 
@@ -299,6 +326,20 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs J) {
   }
 }
 
+// live chunks of a pass (reporting only: pxo_train_backward_work)
+__global__ void count_live_kernel(const uint8_t* __restrict__ fl, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += fl[i] != 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+int launch_count_live(const uint8_t* chunk_live, int64_t n, unsigned long long* out, hipStream_t s) {
+  if (n == 0) return PXO_OK;
+  hipLaunchKernelGGL(count_live_kernel, dim3(64), dim3(256), 0, s, chunk_live, n, out);
+  return check_launch("count_live");
+}
+
 static void split_rows(int64_t M, int64_t target, int64_t* rows_per_wg, int* P) {
   int64_t rpw = (M + target - 1) / target;
   rpw = (rpw + kKC - 1) / kKC * kKC;
@@ -319,17 +360,17 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
 
 template <int NHB>
 static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const float* d_raw_sigma, int C,
-                              int64_t M, int64_t rpw, int P, float* slab, hipStream_t s) {
+                              int64_t M, int64_t rpw, int P, float* slab, const uint8_t* live, hipStream_t s) {
   // 4 waves, each 64 rows x all head columns (4 LDS operand reads per 4 MFMAs instead of 3 per 2), 40 KB of LDS:
   // several workgroups per CU
   hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
-                     d_raw_sigma, C, M, rpw, P, slab);
+                     d_raw_sigma, C, M, rpw, P, slab, (const float*)nullptr, 1, (int64_t)0, live);
 }
 
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
-                           size_t ws_bytes, hipStream_t s) {
+                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s) {
   if (M == 0) return PXO_OK;
   const int deg = cfg->sh_deg;
   const int C = rgb_channels(deg);
@@ -351,15 +392,15 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   const float* h7 = acts + (int64_t)7 * MW;
   auto head = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
-    if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
-    else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
-    else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, s);
+    if (nhb == 1) launch_head_wgrad<1>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, chunk_live, s);
+    else if (nhb == 2) launch_head_wgrad<2>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, chunk_live, s);
+    else launch_head_wgrad<3>(h7, d_raw_rgb, d_raw_sigma, C, M, rpw2, P2, slab, chunk_live, s);
   };
   // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
   auto enc_pair = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
     hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
-                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
+                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW, 1, (int64_t)0, chunk_live);
   };
   float* const g0 = grads + leaf_kernel_off(0, deg);
   float* const g5skip = grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW;
@@ -384,7 +425,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
     hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
-                       acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW);
+                       acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW, chunk_live);
   }
   head(slab_head);
   ReduceJobs J;

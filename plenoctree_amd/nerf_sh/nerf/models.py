@@ -104,7 +104,8 @@ def make_cfg(args):
                         sparsity_weight=args.sparsity_weight, sparsity_length=args.sparsity_length,
                         sparsity_radius=args.sparsity_radius, weight_decay_mult=args.weight_decay_mult,
                         mlp_precision=1 if getattr(args, "mlp_precision", "f32") == "bf16x3" else 0,
-                        noise_std=0.0 if getattr(args, "noise_std", None) is None else args.noise_std)
+                        noise_std=0.0 if getattr(args, "noise_std", None) is None else args.noise_std,
+                        skip_zero_rows=int(bool(getattr(args, "skip_zero_rows", False))))
 
 
 def construct_nerf(args, device, seed=None):

@@ -49,6 +49,9 @@ def define_flags(parser=None):
     # not a reference flag: opt-in split-precision MLP forward for the inference entry points (eval, gen_video, extraction);
     # training is float32 regardless
     a("--mlp_precision", type=str, default="f32", choices=["f32", "bf16x3"])
+    # not a reference flag: leave sample rows whose upstream gradient is exactly zero (empty space, occluded samples,
+    # background rays) out of the reverse pass -- bit-identical gradients, faster steps once the scene has empty space
+    a("--skip_zero_rows", type=_bool, default=True)
     a("--skip_layer", type=int, default=4)
     a("--num_rgb_channels", type=int, default=3)
     a("--num_sigma_channels", type=int, default=1)

@@ -292,6 +292,15 @@ def train_fwd_bwd(cfg, params, packed, origins, directions, viewdirs, pixels, gr
           "pxo_train_fwd_bwd_bucketed")
 
 
+def train_backward_work(cfg, B, ws):
+    """(live, total) 16-row chunks of the reverse pass of the last train_fwd_bwd call on workspace `ws` (synchronises)."""
+    _require_gpu()
+    live, total = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(_lib.load().pxo_train_backward_work(ctypes.byref(cfg), B, _p(ws), ws.numel(), ctypes.byref(live), ctypes.byref(total),
+                                              _stream()), "pxo_train_backward_work")
+    return live.value, total.value
+
+
 class Event:
     """hipEvent_t owned through the C ABI (pxo_event_create): recorded by pxo_train_fwd_bwd_bucketed, waited for by
     `wait(stream)`."""

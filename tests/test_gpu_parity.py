@@ -1075,3 +1075,50 @@ def test_bucketed_gradient_exchange_rides_under_the_fine_level():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("deg,shift,wd", [(3, -2.0, 0.0), (4, -1.0, 0.05), (3, -100.0, 0.0), (3, 0.0, 0.0)])
+def test_skip_zero_rows_is_bit_identical(deg, shift, wd):
+    """PxoCfg.skip_zero_rows: rows whose upstream gradient is exactly zero are left out of backward(data) (whole 128-row tiles)
+    and of the weight-gradient GEMMs (16-row chunks).  Only exact zeros leave the sums, in unchanged order, so gradients
+    and Stats must be BIT-identical to the dense pass -- with most of the volume empty (sigma-head biases lowered by `shift`
+    x the spread of raw sigma), with everything empty (no live chunk at all) and with the ordinary mixture (shift 0)."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg, sparsity_npoints=777, weight_decay_mult=wd)
+    flat = make_params(cfg)
+    n = flat.numel() // 2
+    b8 = sum(fi * fo + fo for fi, fo in O.layer_shapes(cfg)[:8]) + O.layer_shapes(cfg)[8][0]
+    pts = (torch.rand(2048, 3, generator=torch.Generator().manual_seed(4)) * 2 - 1) * 2.0
+    for mi in range(2):
+        _, rs = O.mlp_forward(O.unflatten_params(flat, cfg)[mi], O.posenc(pts, 0, 10), cfg)
+        flat[mi * n + b8] += shift * float(rs.std())
+    B = 600                                        # coarse 38,400 rows = 300 tiles; fine 115,200 + 777 rows: ragged, half tiles
+    rays = make_rays(B)
+    px = torch.rand(B, 3, generator=torch.Generator().manual_seed(2))
+    g = torch.Generator().manual_seed(3)
+    t_rand, u = torch.rand(B, 64, generator=g), torch.rand(B, 128, generator=g)
+    sp = (torch.rand(777, 3, generator=g) * 2 - 1) * 1.5
+    outs = []
+    for skip in (0, 1):
+        pcfg = pxo_cfg(ops, cfg)
+        pcfg.skip_zero_rows = skip
+        fd = flat.to(dev)
+        packed = [ops.pack_weights(pcfg, fd[i * n:(i + 1) * n].contiguous()) for i in range(2)]
+        grads = torch.full_like(fd, float("nan")); stats = torch.zeros(6, device=dev)
+        ws = torch.empty(ops.train_workspace_bytes(pcfg, B), dtype=torch.uint8, device=dev)
+        ws.fill_(0xFF)                              # skipped tiles leave dz unwritten: NaN patterns there must never be read
+        ops.train_fwd_bwd(pcfg, fd, packed, *[r.to(dev) for r in rays], px.to(dev), grads, stats, ws, randomized=True,
+                          t_rand=t_rand.to(dev), u=u.to(dev), sp_points=sp.to(dev))
+        live, total = ops.train_backward_work(pcfg, B, ws)
+        outs.append((grads.cpu(), stats.cpu(), live, total))
+    (g0, s0, l0, t0), (g1, s1, l1, t1) = outs
+    print(f"deg {deg} shift {shift}: live chunks {l1}/{t1} = {l1 / t1:.3f}")
+    assert bool(torch.isfinite(g0).all()) and bool(torch.isfinite(g1).all())
+    assert torch.equal(g0, g1) and torch.equal(s0, s1)
+    assert l0 == t0 == t1 == (B * 64 + 15) // 16 + (B * 192 + 777 + 15) // 16
+    if shift <= -100.0:
+        assert l1 == 0 and float(g1.abs().max()) == 0.0            # nothing is live: the reverse pass is skipped entirely
+    elif shift < 0:
+        assert 0 < l1 < 0.9 * t1, (l1, t1)                          # the case the option exists for (measured 0.32 / 0.84)
+    else:
+        assert l1 <= t1

@@ -70,6 +70,9 @@ def parse(argv=None):
     p.add_argument("--image-factor", type=int, default=0, help="0 = 800x800 views (datasets.Synthetic)")
     p.add_argument("--sparsity-npoints", type=int, default=None, help="dry run only (preset value otherwise)")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = CPU dry run (tests only)")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="with --backend gloo: every rank drives cuda:0 with the REAL kernels (functional check of the N > 1 "
+                        "flow on a 1-GPU box: collectives through gloo, timings meaningless)")
     return p.parse_args(argv)
 
 
@@ -82,7 +85,7 @@ def launch_command(n_gpus, argv, port):
 def self_launch(a, argv):
     """`python bench.py --gpus N` without a launcher: one rank per GPU over RCCL."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < a.gpus:
+    if have < a.gpus and not a.share_gpu:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} ROCm device(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -187,10 +190,11 @@ class Job:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.cuda = a.backend == "nccl"
+        self.cuda = a.backend == "nccl" or a.share_gpu
         if self.cuda:
-            torch.cuda.set_device(self.local_rank)
-            self.device = torch.device("cuda", self.local_rank)
+            dev_index = 0 if a.share_gpu else self.local_rank
+            torch.cuda.set_device(dev_index)
+            self.device = torch.device("cuda", dev_index)
         else:
             self.device = torch.device("cpu")
         self.dist = None
@@ -206,7 +210,7 @@ class Job:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29533 + os.getpid() % 2000))
-        kw = {"device_id": self.device} if self.cuda else {}
+        kw = {"device_id": self.device} if self.a.backend == "nccl" else {}
         dist_mod.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)   # "nccl" = RCCL over xGMI
         self.dist = dist_mod
 
@@ -514,8 +518,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.backend == "nccl" and not torch.cuda.is_available():
+    if (a.backend == "nccl" or a.share_gpu) and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU; the HIP path has no CPU fallback")
+    if a.share_gpu and a.backend != "gloo":
+        raise SystemExit("bench.py --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     job = Job(a)
     rank = job.rank
 
@@ -611,6 +617,9 @@ def main(argv=None):
             out["cpu_baseline"] = cpu
         if not job.cuda:
             out["dry_run"] = "gloo ranks on CPU with the test harness's stand-ins: control flow only, numbers meaningless"
+        elif a.share_gpu:
+            out["dry_run"] = (f"{world} gloo ranks sharing ONE GPU with the real kernels: functional check of the N > 1 flow, "
+                              "timings meaningless")
         print(json.dumps(out), flush=True)
         # RCCL keeps its version banner in the C stdio buffer until the process exits: whatever libraries still flush to
         # fd 1 after this point goes to stderr, so that the JSON line above stays the only line on stdout

@@ -27,12 +27,22 @@ class Comm:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return t
 
+    def _gather_flat(self, out, src):
+        """all_gather of equal-size contiguous `src` into flat `out`.  gloo has no all_gather_into_tensor for device
+        tensors (CPU tests and the shared-GPU functional run use it): list form there."""
+        if self.backend == "gloo" and src.is_cuda:
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, src)
+            torch.cat([p.reshape(-1) for p in parts], out=out.reshape(-1))
+        else:
+            torch.distributed.all_gather_into_tensor(out, src)
+
     def all_gather_cat(self, t):
         """Concatenate equally-shaped per-rank tensors along dim 0, in rank order."""
         if not self.is_dist:
             return t
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        torch.distributed.all_gather_into_tensor(out, t.contiguous())
+        self._gather_flat(out, t.contiguous())
         return out
 
     def all_gather_into(self, out, t):
@@ -43,7 +53,7 @@ class Comm:
         src = t.reshape(-1)
         if self.backend != "nccl":        # RCCL gathers in place when `t` is this rank's slice of `out`; gloo gets a copy
             src = src.clone()
-        torch.distributed.all_gather_into_tensor(out, src)
+        self._gather_flat(out, src)
         return out
 
     def barrier(self):

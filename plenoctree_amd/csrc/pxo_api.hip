@@ -363,7 +363,7 @@ int pxo_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_
   PXO_REQUIRE(M >= 0 && packed_bwd && d_raw_rgb && d_raw_sigma && relu_mask && dz && dbias_partial,
               "pxo_mlp_bwd_data: bad arguments");
   return launch_mlp_bwd_data(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, (const uint32_t*)relu_mask, M, dz,
-                             dbias_partial, nullptr, (hipStream_t)stream);
+                             dbias_partial, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int pxo_wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M, size_t* bytes) {
@@ -563,7 +563,9 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   // skip_zero_rows: rows with an exactly zero upstream gradient are left out of the reverse pass (bit-identical gradients)
   uint8_t* const live_c = cfg->skip_zero_rows ? t.c.live : nullptr;
   uint8_t* const live_f = cfg->skip_zero_rows ? t.f.live : nullptr;
-  PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c, s));
+  unsigned int* const tile_counter = cfg->skip_zero_rows ? reinterpret_cast<unsigned int*>(t.scalars + 100) : nullptr;
+  PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c,
+                              tile_counter, s));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
                                  grads, t.wgrad_ws, t.wgrad_bytes, live_c, s));
   if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads, params, n_mlp, wd_coef, s));
@@ -573,7 +575,8 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   }
   if (Nf > 0) {
     PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
-    PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, live_f, s));
+    PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, live_f,
+                                tile_counter, s));
     PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
                                    grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, live_f, s));
   } else {

@@ -113,8 +113,12 @@ __host__ __device__ inline int64_t mask_slots(int64_t M) { return num_tiles(M) +
 __host__ __device__ inline int64_t mask_words(int64_t M) {
   return mask_slots(M) * kDepth * kMlpThreads * kMaskWords;
 }
-// bias-gradient partials written by the backward-data kernel, one per persistent workgroup: [wg][9][256]
-__host__ __device__ inline int64_t dbias_floats(int64_t M) { (void)M; return (int64_t)kMaxMlpGrid * 9 * kW; }
+// bias-gradient partials written by the backward-data kernel, one per TILE SLOT: [slot][9][256] (a tile's column sums do
+// not depend on which workgroup computed it, so any tile schedule gives the same bits), + one live byte per slot behind
+__host__ __device__ inline int64_t dbias_floats(int64_t M) { return mask_slots(M) * (9 * kW + 1); }
+__host__ __device__ inline const uint8_t* dbias_tile_live(const float* dbias_partial, int64_t M) {
+  return reinterpret_cast<const uint8_t*>(dbias_partial + mask_slots(M) * 9 * kW);
+}
 
 // ---- error plumbing ------------------------------------------------------------------
 void set_error(const char* fmt, ...);
@@ -130,7 +134,7 @@ int check_launch(const char* what);
 
 int validate_cfg(const PxoCfg* cfg);
 int num_cus();
-int mlp_bwd_partials(int64_t M);   // number of [9][256] partials mlp_bwd_data writes for M rows
+int mlp_bwd_partials(int64_t M);   // number of [9][256] tile partials (slots) mlp_bwd_data writes for M rows
 
 // HIP-event bracket around one kernel launch (active only after pxo_profile_enable(1))
 struct KernelTimer {
@@ -150,9 +154,11 @@ int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts,
 // chunk_live (may be NULL = dense): one byte per kLiveRows rows, WRITTEN by the backward(data) kernel (1: some row of the
 // chunk has a non-zero upstream gradient) and READ by the weight-gradient kernels, which skip dead chunks
 __host__ __device__ inline int64_t live_flags(int64_t M) { return (M + kLiveRows - 1) / kLiveRows + kTM / kLiveRows; }
+// tile_counter (skipping mode only, may be NULL): a zeroed device word; the persistent workgroups then TAKE tiles from it
+// instead of striding over them, so that skipped tiles do not leave workgroups idle
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
-                        float* dbias_partial, uint8_t* chunk_live, hipStream_t s);
+                        float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s);
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,

@@ -265,7 +265,8 @@ struct ReduceJob {
 };
 struct ReduceJobs {
   ReduceJob job[kDepth + 1];                    // Dense_1..7, enc-based pair (Dense_0 | Dense_5 skip rows), heads
-  const float* dbias_partial;                   // + the bias gradients as job kDepth + 1
+  const float* dbias_partial;                   // + the bias gradients as job kDepth + 1: [slot][9][256] tile partials
+  const uint8_t* tile_live;                     //   one byte per slot (0: the tile was skipped, its partial was not written)
   int64_t dbias_tiles;
   int deg;
   float* grads;
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs J) {
     const int c = threadIdx.x & 31, tsub = threadIdx.x >> 5;
     const int col = cg * 32 + c;
     float s = 0.f;
-    for (int64_t t = tsub; t < J.dbias_tiles; t += 8) s += J.dbias_partial[(t * 9 + l) * kW + col];
+    for (int64_t t = tsub; t < J.dbias_tiles; t += 8)
+      if (J.tile_live[t]) s += J.dbias_partial[(t * 9 + l) * kW + col];
     redb[tsub][c] = s;
     __syncthreads();
     if (tsub == 0) {
@@ -435,6 +437,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   J.job[NL] = ReduceJob{slab_enc, P2, kEncPad, 2 * kW, kEnc, g0, 0, kW, kW, g5skip, kW, kW, kW};
   J.job[NL + 1] = ReduceJob{slab_head, P2, kW, 32 * nhb, kW, g9, 0, C, C, g8, C, 1, 1};
   J.dbias_partial = dbias_partial;
+  J.tile_live = dbias_tile_live(dbias_partial, M);
   J.dbias_tiles = (int64_t)mlp_bwd_partials(M);
   J.deg = deg;
   J.grads = grads;

@@ -93,7 +93,7 @@ def test_size_queries(lib):
     slot = 8 * 128 * 256 // 8
     assert lib.pxo_relu_mask_bytes(128) == (1 + 512) * slot
     assert lib.pxo_relu_mask_bytes(129) == (2 + 512) * slot
-    assert lib.pxo_dbias_partial_bytes(128) == 1024 * 9 * 256 * 4   # one [9][256] slot per persistent workgroup
+    assert lib.pxo_dbias_partial_bytes(128) == (1 + 512) * (9 * 256 + 1) * 4   # one [9][256] partial + a live byte per tile slot
     nbytes = ctypes.c_size_t(0)
     assert lib.pxo_train_workspace_bytes(ctypes.byref(cfg), 4096, ctypes.byref(nbytes)) == 0
     # dominated by saved activations + dz: 2 * 8 layers * (4096*256 + 10000) rows * 1 KiB

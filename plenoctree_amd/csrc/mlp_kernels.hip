@@ -716,7 +716,7 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // ------------------------------------------------------------------------------------------
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
-template <int NHB, int RBN>
+template <int NHB, int RBN, bool SKIP>
 __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restrict__ db_slot, uint8_t* __restrict__ tile_live,
                                          const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
                                          const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask,
@@ -731,8 +731,8 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   const ARows arow = make_arows(lds, lane);
   const WImage wimg = make_wimage(pkb, bwd_image_floats(deg), lane);
   lds_barrier();   // previous tile's stores out of LDS are done
-  if (chunk_live && tid < kChunks) nz[tid] = 0;
-  if (chunk_live) lds_barrier();
+  if (SKIP && tid < kChunks) nz[tid] = 0;
+  if (SKIP) lds_barrier();
   // d_raw tile -> lds[:, 0:NH] with the head's column order (d_raw_rgb == NULL: sigma-only rows)
   for (int idx = tid; idx < kRows * NH; idx += kMlpThreads) {
     const int row = idx / NH, col = idx - row * NH;
@@ -743,10 +743,10 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
       else if (col == C) v = d_raw_sigma[grow];
     }
     lds[row * kLDA + col] = v;
-    if (chunk_live && v != 0.f) nz[row / kLiveRows] = 1;          // same value from every writer
+    if (SKIP && v != 0.f) nz[row / kLiveRows] = 1;                // same value from every writer
   }
   lds_barrier();
-  if (chunk_live) {
+  if (SKIP) {
     // Rows whose upstream gradient (d_raw_rgb, d_raw_sigma) is exactly zero -- samples in empty space (relu(sigma) = 0
     // and weight 0), samples behind an opaque surface, every sample of a background ray -- have dz_l = 0 in every layer
     // and add exactly 0 to every weight and bias gradient.  Per 16-row chunk a flag says whether any row is live: the
@@ -818,7 +818,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   }
 }
 
-template <int NHB>
+template <int NHB, bool SKIP>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg, TileSched ts,
@@ -836,13 +836,13 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   auto run = [&](int64_t slot) {
     float* db = dbias_partial + slot * 9 * kW;
     if (slot < ts.n_full)
-      bwd_tile<NHB, kRB>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, slot * kTM, slot, dz, nz,
-                         chunk_live, tid, lane, wave);
+      bwd_tile<NHB, kRB, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, slot * kTM, slot, dz, nz,
+                               chunk_live, tid, lane, wave);
     else
-      bwd_tile<NHB, kRB / 2>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
+      bwd_tile<NHB, kRB / 2, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
                              ts.half_row0 + (slot - ts.n_full) * (kTM / 2), slot, dz, nz, chunk_live, tid, lane, wave);
   };
-  if (tile_counter == nullptr) {
+  if (!SKIP || tile_counter == nullptr) {
     for (int64_t slot = blockIdx.x; slot < ts.n_full; slot += gridDim.x) run(slot);
     for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x) run(ts.n_full + h);
   } else {
@@ -876,20 +876,21 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
   const TileSched ts = tile_sched(M, grid_dim.x);
+#define PXO_BWD(NHB_)                                                                                                   \
+  do {                                                                                                                   \
+    if (chunk_live)                                                                                                      \
+      hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB_, true>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,   \
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);                         \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB_, false>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,  \
+                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);                         \
+  } while (0)
   switch (head_blocks(cfg->sh_deg)) {
-    case 1:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<1>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);
-      break;
-    case 2:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<2>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);
-      break;
-    default:
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<3>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);
-      break;
+    case 1: PXO_BWD(1); break;
+    case 2: PXO_BWD(2); break;
+    default: PXO_BWD(3); break;
   }
+#undef PXO_BWD
   return check_launch("mlp_bwd_data");
 }
 

@@ -21,7 +21,8 @@ constexpr int kKC = 32;           // row granularity of the split (rows_per_wg i
 // row range are placed 8 blocks apart = on the same XCD so the second read of X hits L2).
 // DUAL: the NOUT = 512 columns are two row-major [M,256] arrays side by side (dZ | dZ2): Dense_0 and the skip rows of
 // Dense_5 share X = enc (model_utils.py:70-71), so one pass over enc produces both gradients.
-template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false, int SCHED = 0>
+template <int KIN, int NOUT, int WR, int WC, bool HEAD, int NT, int KCH, int NSPLIT, bool DUAL = false, int SCHED = 0,
+          bool SPARSE = false>
 __global__ __launch_bounds__(NT) void wgrad_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, const float* __restrict__ d_raw_sigma,
     int C, int64_t M, int64_t rows_per_wg, int P, float* __restrict__ slab, const float* __restrict__ dZ2 = nullptr,
@@ -202,16 +203,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     __syncthreads();
   };
 
-  // Zero-row skipping (chunk_live != NULL): the backward(data) kernel flagged every 16-row chunk that has a row with a
-  // non-zero upstream gradient; all other rows have dz = 0 in every layer (and may not even have been written), so their
-  // chunks add exactly nothing.  Wave 0 compacts the range's live chunks, in order, into an LDS list; the loop then walks
-  // the list instead of 0..nchunks-1 (same accumulation order over the chunks that contribute: bit-identical sums).
-  constexpr int kMaxLive = 2048;                       // longer ranges (> 32 k rows) run dense
+  // Zero-row skipping (SPARSE instantiation, chunk_live != NULL): the backward(data) kernel flagged every 16-row chunk that
+  // has a row with a non-zero upstream gradient; all other rows have dz = 0 in every layer (and may not even have been
+  // written), so their chunks add exactly nothing.  Wave 0 compacts the range's live chunks, in order, into an LDS list; the
+  // loop then walks the list instead of 0..nchunks-1 (same accumulation order over the chunks that contribute: bit-identical
+  // sums).  A separate instantiation: in the dense kernel the chunk index stays the loop counter (a scalar; as a value read
+  // from LDS it cost the dense 256x256 product 5 %, measured).
+  constexpr int kMaxLive = SPARSE ? 2048 : 1;          // longer ranges (> 32 k rows) run dense
   __shared__ uint16_t live_list[kMaxLive];
   __shared__ int live_count;
-  const bool sparse = chunk_live != nullptr && nchunks <= kMaxLive;
+  const bool sparse = SPARSE && chunk_live != nullptr && nchunks <= kMaxLive;
   int n_run = nchunks;
-  if (sparse) {
+  if (SPARSE && sparse) {
     if (wave == 0) {
       const uint8_t* fl = chunk_live + r_begin / KCH;
       int base = 0;
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
     __syncthreads();
     n_run = live_count;
   }
-  auto chunk_at = [&](int i) { return sparse ? (int)live_list[i] : i; };
+  auto chunk_at = [&](int i) -> int {
+    if (SPARSE && sparse) return __builtin_amdgcn_readfirstlane((int)live_list[i]);
+    return i;
+  };
   {
     Stage st;
     if (n_run > 0) {
@@ -274,21 +280,40 @@ struct ReduceJobs {
 
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs J) {
   __shared__ f32x4 red[4][64];
-  if (blockIdx.y == kDepth + 1) {               // bias gradients: block = (layer 0..8, 32-column group)
-    if (blockIdx.x >= 9 * 8) return;
-    float (*redb)[32] = reinterpret_cast<float (*)[32]>(&red[0][0]);
-    const int l = blockIdx.x / 8, cg = blockIdx.x % 8;
-    const int c = threadIdx.x & 31, tsub = threadIdx.x >> 5;
-    const int col = cg * 32 + c;
+  if (blockIdx.y == kDepth + 1) {
+    // bias gradients: block = (layer 0..8, 8-column group), 32 sub-threads per column stride over the tile slots with 8
+    // independent loads in flight (the slots are thousands at 4096 rays: a serial loop over them is pure latency), then a
+    // fixed-order LDS sum.  Dead slots (tile_live == 0: skipped tiles, whose partial was never written) are left out; a
+    // live tile's partial of a dead ROW range is an exact zero, so dense and skipping passes give the same bits.
+    if (blockIdx.x >= 9 * 32) return;
+    float (*redb)[8] = reinterpret_cast<float (*)[8]>(&red[0][0]);
+    const int l = blockIdx.x / 32, cg = blockIdx.x % 32;
+    const int c = threadIdx.x & 7, tsub = threadIdx.x >> 3;
+    const int col = cg * 8 + c;
+    const int64_t n = J.dbias_tiles;
     float s = 0.f;
-    for (int64_t t = tsub; t < J.dbias_tiles; t += 8)
-      if (J.tile_live[t]) s += J.dbias_partial[(t * 9 + l) * kW + col];
+    for (int64_t t0 = tsub; t0 < n; t0 += 32 * 8) {
+      bool lv[8];
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t t = t0 + 32 * k;
+        lv[k] = t < n && J.tile_live[t] != 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t t = t0 + 32 * k;
+        v[k] = lv[k] ? J.dbias_partial[(t * 9 + l) * kW + col] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
     redb[tsub][c] = s;
     __syncthreads();
     if (tsub == 0) {
       float tot = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) tot += redb[i][c];
+      for (int i = 0; i < 32; ++i) tot += redb[i][c];
       if (l < 8) {
         J.grads[leaf_bias_off(l, J.deg) + col] = tot;
       } else {
@@ -365,8 +390,12 @@ static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const floa
                               int64_t M, int64_t rpw, int P, float* slab, const uint8_t* live, hipStream_t s) {
   // 4 waves, each 64 rows x all head columns (4 LDS operand reads per 4 MFMAs instead of 3 per 2), 40 KB of LDS:
   // several workgroups per CU
-  hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
-                     d_raw_sigma, C, M, rpw, P, slab, (const float*)nullptr, 1, (int64_t)0, live);
+  if (live)
+    hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1, true>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
+                       d_raw_sigma, C, M, rpw, P, slab, (const float*)nullptr, 1, (int64_t)0, live);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<kW, 32 * NHB, 4, 1, true, 256, 16, 1, false, 1>), dim3(P), dim3(256), 0, s, X, d_raw_rgb,
+                       d_raw_sigma, C, M, rpw, P, slab);
 }
 
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
@@ -401,8 +430,12 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // Dense_0 and the skip rows 256..318 of Dense_5 in one pass over enc: enc^T [dz_0 | dz_5]  (63 valid input rows)
   auto enc_pair = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
-    hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
-                       nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW, 1, (int64_t)0, chunk_live);
+    if (chunk_live)
+      hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1, true>), dim3(P2), dim3(256), 0, s, enc, dz,
+                         nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW, 1, (int64_t)0, chunk_live);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<kEncPad, 2 * kW, 1, 4, false, 256, 16, 1, true, 1>), dim3(P2), dim3(256), 0, s, enc, dz,
+                         nullptr, 0, M, rpw2, P2, slab, dz + (int64_t)5 * MW);
   };
   float* const g0 = grads + leaf_kernel_off(0, deg);
   float* const g5skip = grads + leaf_kernel_off(5, deg) + (int64_t)kW * kW;
@@ -426,8 +459,12 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   enc_pair(slab_enc);
   {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
-    hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
-                       acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW, chunk_live);
+    if (chunk_live)
+      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2, false, 0, true>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256),
+                         0, s, acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW, chunk_live);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256), 0, s,
+                         acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW);
   }
   head(slab_head);
   ReduceJobs J;
@@ -443,7 +480,7 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   J.grads = grads;
   // (Issuing the coarse pass's reduction on a lowest-priority side stream, to run in the tail of the fine pass's backward
   // kernel, was measured in round 3: 3.896 vs 3.904 ms per step at 512 rays, 25.26 vs 25.23 at 4096 -- nothing; not kept.)
-  hipLaunchKernelGGL(reduce_jobs_kernel, dim3(kW * kW / 4 / 64, kDepth + 2), dim3(256), 0, s, J);
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3(9 * 32 > kW * kW / 4 / 64 ? 9 * 32 : kW * kW / 4 / 64, kDepth + 2), dim3(256), 0, s, J);
   return check_launch("mlp_bwd_weights");
 }
 

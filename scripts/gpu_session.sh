@@ -89,7 +89,8 @@ for stage in ${STAGES:-tests bench}; do
     done ;;
   ab_trees)
     : > gpurun_out/ab_trees.txt
-    for B in ${BATCHES:-512}; do for r in $(seq 1 ${ROUNDS:-3}); do for t in ${TREES:-"_ab_base ."}; do
+    TREES_=${TREES:-_ab_base .}
+    for B in ${BATCHES:-512}; do for r in $(seq 1 ${ROUNDS:-3}); do for t in $TREES_; do
       ( cd "$R/$t" && timeout 300 python bench.py --batch $B --steps ${AB_STEPS:-60} --warmup 5 $HEAD_ARGS ${AB_ARGS:-} 2> /dev/null ) > gpurun_out/ab_run.json
       brief gpurun_out/ab_run.json "$t" $B | tee -a gpurun_out/ab_trees.txt
     done; done; done

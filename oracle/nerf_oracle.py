@@ -36,7 +36,8 @@ Parity status
   rounding, leaf by leaf (tests/test_oracle_golden.py).
 * Adam (flax.optim) remains "PARITY UNPINNED": flax cannot be imported here and the
   reference ships no vectors for it; `adam_update` restates the published rule and is
-  pinned only by closed-form known answers (tests/test_oracle_known_answers.py).
+  pinned only by closed-form known answers and by agreement with torch.optim.Adam, an independent
+  implementation of the same published rule (tests/test_oracle_known_answers.py).
 * flax.optim.Adam is third-party (flax>=0.3.1, environment.yml:19; call sites
   nerf_sh/nerf/models.py:44, nerf_sh/train.py:119); its published update rule
   is restated in `adam_update`.

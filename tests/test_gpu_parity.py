@@ -482,6 +482,18 @@ def test_adam_step():
     close("adam/p", pd, p, rtol=1e-6, atol=1e-7)
     close("adam/m", md, m, rtol=1e-6, atol=1e-9)
     close("adam/v", vd, v, rtol=1e-6, atol=1e-12)
+    # and against torch.optim.Adam: independent code for the same published rule (eps outside the root, both moments
+    # bias-corrected), float64, the same gradients and learning rates
+    gen = torch.Generator().manual_seed(31)
+    ref = torch.randn(n, generator=gen).double().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1.0, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(3):
+        g = torch.randn(n, generator=gen) * 10 ** (-step)
+        for group in opt.param_groups:
+            group["lr"] = O.learning_rate_decay(step, 5e-4, 5e-6, 1000)
+        ref.grad = g.double()
+        opt.step()
+    close("adam/p vs torch.optim.Adam", pd, ref.detach(), rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("deg,randomized", [(3, True), (3, False), (4, True)])

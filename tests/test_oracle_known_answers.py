@@ -193,3 +193,25 @@ def test_chunked_oracle_helpers_match_the_oracle():
     for lvl in range(2):
         for j in range(3):
             assert torch.equal(ref[lvl][j], got[lvl][j])
+
+
+def test_adam_against_an_independent_implementation_of_the_same_rule():
+    """flax.optim.Adam (flax>=0.3.1, call sites nerf_sh/nerf/models.py:44, nerf_sh/train.py:119) cannot be imported here, so
+    `adam_update` restates its published rule: m, v EMAs, both bias-corrected, eps added to sqrt(v_hat) (OUTSIDE the root).
+    torch.optim.Adam implements the same rule (Kingma & Ba, Algorithm 1; eps outside the root, bias correction of both
+    moments, no weight decay, no amsgrad) in independent code: 6 steps with a changing learning rate must agree to float64
+    round-off.  Not a flax pin -- a second implementation of the published rule that the oracle did not write."""
+    gen = torch.Generator().manual_seed(5)
+    p0 = torch.randn(1000, generator=gen, dtype=torch.float64)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1.0, betas=(0.9, 0.999), eps=1e-8)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for step in range(6):
+        g = torch.randn(1000, generator=gen, dtype=torch.float64) * 10.0 ** (-(step % 3))
+        lr = O.learning_rate_decay(step, 5e-4, 5e-6, 10)
+        for group in opt.param_groups:
+            group["lr"] = lr
+        ref.grad = g.clone()
+        opt.step()
+        p, m, v = O.adam_update(p, m, v, g, lr, step)
+        np.testing.assert_allclose(p.numpy(), ref.detach().numpy(), rtol=1e-12, atol=1e-15)

@@ -21,24 +21,6 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
-// sum of squares in two fixed-order stages (weight_l2, train.py:101-108)
-constexpr int kSumsqBlocks = 64;
-__global__ __launch_bounds__(kRedThreads) void sumsq_stage1(const float* __restrict__ x, int64_t n,
-                                                            float* __restrict__ partial) {
-  __shared__ float red[kRedThreads];
-  float s = 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)kRedThreads + threadIdx.x; i < n; i += (int64_t)kSumsqBlocks * kRedThreads)
-    s += x[i] * x[i];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-// out: kSumsqBlocks partial sums (fixed order; finalize_stats adds them)
-int launch_sumsq_partials(const float* x, int64_t n, float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(sumsq_stage1, dim3(kSumsqBlocks), dim3(kRedThreads), 0, s, x, n, partial);
-  return check_launch("sumsq");
-}
-int sumsq_partials() { return kSumsqBlocks; }
-
 // Stats (nerf_sh/nerf/utils.py:43-50): loss, psnr, loss_c, loss_sp, psnr_c, weight_l2 from the per-ray squared
 // errors of the two passes (shade_composite_train_kernel), the per-point exp(-len relu(sigma)) of the sparsity rows
 // and the partial sums of squares of the parameters -- every sum in a fixed order (deterministic).

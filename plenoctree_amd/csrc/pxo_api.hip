@@ -4,7 +4,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,62 +76,6 @@ KernelTimer::KernelTimer(int tag, int64_t rows, hipStream_t s) : slot(-1), strea
 KernelTimer::~KernelTimer() {
   if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
 }
-
-// Side stream of pxo_train_fwd_bwd: the parameter norm (weight_l2) depends on the parameters only and is issued beside
-// the forward pass, between a fork event on the caller's stream and a join back into it.  One set per device, created
-// under a lock on first use for the device that is current at the call, never destroyed.
-struct SideStreams {
-  static constexpr int kN = 1;
-  hipStream_t s[kN] = {nullptr};
-  hipEvent_t fork[1] = {}, join[1][kN] = {};
-  bool ok = false;
-};
-static SideStreams* side_streams() {
-  constexpr int kMaxDevices = 64;
-  static SideStreams table[kMaxDevices];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  SideStreams& ss = table[dev];
-  if (!ss.ok) {
-    bool good = true;
-    for (int i = 0; i < SideStreams::kN; ++i) good = good && hipStreamCreateWithFlags(&ss.s[i], hipStreamNonBlocking) == hipSuccess;
-    for (int f = 0; f < 1; ++f) {
-      good = good && hipEventCreateWithFlags(&ss.fork[f], hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; i < SideStreams::kN; ++i)
-        good = good && hipEventCreateWithFlags(&ss.join[f][i], hipEventDisableTiming) == hipSuccess;
-    }
-    if (!good) {          // nothing half-made is kept: the next call starts from scratch
-      for (int i = 0; i < SideStreams::kN; ++i) if (ss.s[i]) { (void)hipStreamDestroy(ss.s[i]); ss.s[i] = nullptr; }
-      for (int f = 0; f < 1; ++f) {
-        if (ss.fork[f]) { (void)hipEventDestroy(ss.fork[f]); ss.fork[f] = nullptr; }
-        for (int i = 0; i < SideStreams::kN; ++i) if (ss.join[f][i]) { (void)hipEventDestroy(ss.join[f][i]); ss.join[f][i] = nullptr; }
-      }
-      return nullptr;
-    }
-    ss.ok = true;
-  }
-  return &ss;
-}
-// fork point `f`: side stream i may start once everything issued so far on `main` is done
-static bool fork_to(SideStreams& ss, int f, hipStream_t main, int i) {
-  return hipEventRecord(ss.fork[f], main) == hipSuccess && hipStreamWaitEvent(ss.s[i], ss.fork[f], 0) == hipSuccess;
-}
-// join: `main` waits for everything issued so far on side stream i
-static bool join_from(SideStreams& ss, int f, hipStream_t main, int i) {
-  return hipEventRecord(ss.join[f][i], ss.s[i]) == hipSuccess && hipStreamWaitEvent(main, ss.join[f][i], 0) == hipSuccess;
-}
-// Once a fork succeeded the caller's stream must re-join the side stream on EVERY exit path: a failed launch further
-// down would otherwise return with the side kernel unordered against whatever the caller does next with `params`
-// (and an enclosing stream capture would be left forked).
-struct JoinGuard {
-  SideStreams& ss;
-  hipStream_t main;
-  bool armed = true;
-  ~JoinGuard() { if (armed) (void)join_from(ss, 0, main, 0); }
-  bool join() { armed = false; return join_from(ss, 0, main, 0); }
-};
 
 // bump allocator over the caller's workspace; with base == nullptr it only measures
 struct Carver {
@@ -237,7 +180,8 @@ struct Draws { const float* t_rand; const float* u; bool noisy; uint64_t seed; }
 
 // every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
 static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomized, const float* t_rand, const float* u,
-                         const float* sp_points, uint64_t seed, hipStream_t s, Draws& out) {
+                         const float* sp_points, uint64_t seed, hipStream_t s, Draws& out, const float* params = nullptr,
+                         int64_t n_params = 0, float* sumsq_partial = nullptr) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PassBuffers& last = Nf > 0 ? t.f : t.c;
   UniformJob jobs[3];
@@ -259,7 +203,7 @@ static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomize
   out.t_rand = t_rand; out.u = u;
   out.noisy = randomized != 0 && cfg->noise_std > 0.f;     // (noise_std is not None) and randomized, model_utils.py:329
   out.seed = seed;
-  return launch_uniform_jobs(seed, jobs, nj, s);
+  return launch_uniform_jobs(seed, jobs, nj, s, params, n_params, sumsq_partial);
 }
 
 static int forward_coarse(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* o, const float* d, const float* v,
@@ -546,16 +490,11 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   const int deg = cfg->sh_deg;
   const int64_t n_mlp = mlp_param_count(deg);
   const float wd_coef = 2.f * cfg->weight_decay_mult / (float)(2 * n_mlp);   // d/dp of weight_decay_mult * sum(p^2)/n (train.py:101-114)
-  SideStreams* ssp = side_streams();
-  if (!ssp) { set_error("pxo_train_fwd_bwd: could not create the side streams"); return PXO_ERR_HIP; }
-  SideStreams& ss = *ssp;
-  // weight_l2 = sum(p^2) / n (train.py:101-108) depends on the parameters only: its partial sums run beside the forward pass
+  // weight_l2 = sum(p^2) / n (train.py:101-108) depends on the parameters only: its partial sums ride in the step's first
+  // launch, together with every uniform draw
   float* const sumsq_partial = t.scalars;
-  if (!fork_to(ss, 0, s, 0)) { set_error("pxo_train_fwd_bwd: stream fork failed"); return PXO_ERR_HIP; }
-  JoinGuard guard{ss, s};
-  PXO_TRY(launch_sumsq_partials(params, 2 * n_mlp, sumsq_partial, ss.s[0]));
   Draws dr;
-  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, sp_points, seed, s, dr));
+  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, sp_points, seed, s, dr, params, 2 * n_mlp, sumsq_partial));
   // coarse level: forward, losses (train.py:77-98), reverse of the compositing, reverse through MLP_0.  Nothing of the fine
   // level feeds MLP_0's gradient (the fine sample positions carry no gradient, model_utils.py:286), so it is complete here
   // -- a quarter into the step -- and its all-reduce can ride under the fine level.
@@ -583,7 +522,6 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
     PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
   }
   if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads + n_mlp, params + n_mlp, n_mlp, wd_coef, s));
-  if (!guard.join()) { set_error("pxo_train_fwd_bwd: stream join failed"); return PXO_ERR_HIP; }
   PXO_TRY(launch_finalize_stats(Nf > 0 ? t.f.ray_sse : nullptr, t.c.ray_sse, t.n_sp > 0 ? t.sp_exp : nullptr, sumsq_partial,
                                 B, t.n_sp, cfg->sparsity_weight, 2 * n_mlp, stats, s));
   return PXO_OK;

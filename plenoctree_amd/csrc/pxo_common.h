@@ -202,8 +202,11 @@ int launch_shade_composite_train(const PxoCfg* cfg, const float* raw_rgb, const 
                                  int64_t n_sp, float* sp_exp, hipStream_t s);
 // up to 3 uniform draws (Philox streams of one seed) in one launch
 struct UniformJob { uint64_t stream_id; int64_t n; float lo, hi; float* out; };
-int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s);
-int launch_sumsq_partials(const float* x, int64_t n, float* partial, hipStream_t s);   // 64 partial sums
+// sq_x != NULL: the same launch also writes the kSumsqBlocks fixed-order partial sums of squares of sq_x[0 .. sq_n) (the
+// parameter norm of weight_l2, train.py:101-108: it depends on the parameters only, so it rides with the step's first launch)
+constexpr int kSumsqBlocks = 64;
+int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s, const float* sq_x = nullptr,
+                        int64_t sq_n = 0, float* sq_partial = nullptr);
 int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* sp_exp, const float* sumsq_partial,
                           int64_t B, int64_t n_sp, float sp_weight, int64_t n_params, float* stats, hipStream_t s);
 int launch_adam_pack(const PxoCfg* cfg, float* p, float* m, float* v, const float* g, float lr, int64_t step,

@@ -582,11 +582,28 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
 }
 
-struct UniformJobs { UniformJob job[3]; };
+struct UniformJobs { UniformJob job[3]; int n_jobs; const float* sq_x; int64_t sq_n; float* sq_partial; };
 
 // blockIdx.y selects the job; element idx of a job is word idx % 4 of the Philox block with counter idx / 4 and the
 // job's stream id in the upper counter words
-__global__ void uniform_kernel(uint64_t seed, UniformJobs J) {
+__global__ __launch_bounds__(256) void uniform_kernel(uint64_t seed, UniformJobs J) {
+  if ((int)blockIdx.y == J.n_jobs) {
+    // parameter-norm partials (weight_l2 = sum(p^2) / n, train.py:101-108): kSumsqBlocks blocks, strided loads, fixed-order
+    // tree in LDS; finalize_stats_kernel adds the partials in order
+    if (blockIdx.x >= kSumsqBlocks) return;
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < J.sq_n; i += (int64_t)kSumsqBlocks * 256)
+      acc += J.sq_x[i] * J.sq_x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) J.sq_partial[blockIdx.x] = red[0];
+    return;
+  }
   const UniformJob& jb = J.job[blockIdx.y];
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (q * 4 >= jb.n) return;
@@ -634,7 +651,8 @@ int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, 
   return check_launch("randint");
 }
 
-int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s) {
+int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s, const float* sq_x, int64_t sq_n,
+                        float* sq_partial) {
   UniformJobs J;
   int64_t qmax = 0;
   int nj = 0;
@@ -644,9 +662,13 @@ int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipSt
     const int64_t q = (jobs[i].n + 3) / 4;
     if (q > qmax) qmax = q;
   }
-  if (nj == 0) return PXO_OK;
+  const bool sq = sq_x != nullptr && sq_partial != nullptr;
+  if (nj == 0 && !sq) return PXO_OK;
   for (int i = nj; i < 3; ++i) J.job[i] = UniformJob{0, 0, 0.f, 0.f, nullptr};
-  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((qmax + 255) / 256), nj), dim3(256), 0, s, seed, J);
+  J.n_jobs = nj; J.sq_x = sq_x; J.sq_n = sq_n; J.sq_partial = sq_partial;
+  int64_t bx = (qmax + 255) / 256;
+  if (sq && bx < kSumsqBlocks) bx = kSumsqBlocks;
+  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)bx, nj + (sq ? 1 : 0)), dim3(256), 0, s, seed, J);
   return check_launch("uniform");
 }
 

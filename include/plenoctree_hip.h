@@ -203,6 +203,14 @@ int pxo_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int
 int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t* pixel_ids, int64_t B,
                       float* origins, float* directions, float* viewdirs, void* stream);
 
+/* Dataset._next_train for one image (nerf_sh/nerf/datasets.py:159-166: `ray_indices = np.random.randint(0, H*W, (B,))`, the
+ * rays and the pixels of those indices) in one launch: pixel id i = pxo_randint's element i of stream (seed, stream_id)
+ * mod W*H, its ray as pxo_generate_rays, its colour from image_rgb [H*W,3] (the resident training image) -- bit for bit what
+ * the three separate calls give.  pixel_ids [B] may be NULL. */
+int pxo_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal,
+                     const float* image_rgb, int64_t B, int64_t* pixel_ids, float* origins, float* directions,
+                     float* viewdirs, float* pixels, void* stream);
+
 /* The same for the `image_batching` sampler (nerf_sh/nerf/datasets.py:137-141,152-157: rays of ALL
  * images flattened into one table): c2w [n_cams,3,4], ray id r -> camera r / (W*H), pixel r % (W*H). */
 int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids,

@@ -397,6 +397,16 @@ int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t
   return launch_generate_rays(c2w, 1, W, H, focal, pixel_ids, B, origins, directions, viewdirs, (hipStream_t)stream);
 }
 
+int pxo_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal, const float* image_rgb,
+                     int64_t B, int64_t* pixel_ids, float* origins, float* directions, float* viewdirs, float* pixels,
+                     void* stream) {
+  if (B == 0) return PXO_OK;
+  PXO_REQUIRE(B >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && image_rgb && origins && directions && viewdirs && pixels,
+              "pxo_sample_batch: bad arguments");
+  return launch_sample_batch(seed, stream_id, c2w, W, H, focal, image_rgb, B, pixel_ids, origins, directions, viewdirs, pixels,
+                             (hipStream_t)stream);
+}
+
 int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids, int64_t B,
                             float* origins, float* directions, float* viewdirs, void* stream) {
   if (B == 0) return PXO_OK;

@@ -505,6 +505,24 @@ int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const 
 // ------------------------------------------------------------------------------------------
 // With n_cams > 1 the ids index the flattened [n_cams, H*W] ray table of the image_batching sampler
 // (nerf_sh/nerf/datasets.py:137-141,152-157) and c2w is [n_cams,3,4].
+// ray of pixel p of the camera c2w, written to row i (generate_rays, nerf_sh/nerf/utils.py:545-589, pinhole branch)
+__device__ __forceinline__ void pixel_ray(const float* __restrict__ c2w, int W, int H, float focal, int64_t p, int64_t i,
+                                          float* __restrict__ o, float* __restrict__ d, float* __restrict__ v) {
+  const float x = (float)(p % W), y = (float)(p / W);
+  const float cx = (x - (float)W * 0.5f) / focal, cy = -(y - (float)H * 0.5f) / focal, cz = -1.f;
+  float dir[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // numpy matmul accumulates the 3 products in order
+    dir[a] = c2w[a * 4 + 0] * cx + c2w[a * 4 + 1] * cy + c2w[a * 4 + 2] * cz;
+    o[i * 3 + a] = c2w[a * 4 + 3];
+    d[i * 3 + a] = dir[a];
+  }
+  const float n = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[i * 3 + a] = dir[a] / n;
+}
+
 __global__ void generate_rays_kernel(const float* __restrict__ c2w_all, int n_cams, int W, int H, float focal,
                                      const int64_t* __restrict__ pix, int64_t B, float* __restrict__ o,
                                      float* __restrict__ d, float* __restrict__ v) {
@@ -519,19 +537,7 @@ __global__ void generate_rays_kernel(const float* __restrict__ c2w_all, int n_ca
     p -= cam * hw;
     c2w += cam * 12;
   }
-  const float x = (float)(p % W), y = (float)(p / W);
-  const float cx = (x - (float)W * 0.5f) / focal, cy = -(y - (float)H * 0.5f) / focal, cz = -1.f;
-  float dir[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    // numpy matmul accumulates the 3 products in order
-    dir[a] = c2w[a * 4 + 0] * cx + c2w[a * 4 + 1] * cy + c2w[a * 4 + 2] * cz;
-    o[i * 3 + a] = c2w[a * 4 + 3];
-    d[i * 3 + a] = dir[a];
-  }
-  const float n = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-#pragma unroll
-  for (int a = 0; a < 3; ++a) v[i * 3 + a] = dir[a] / n;
+  pixel_ray(c2w, W, H, focal, p, i, o, d, v);
 }
 
 int launch_generate_rays(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* pix, int64_t B,
@@ -649,6 +655,40 @@ int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, 
   const int64_t q = (count + 1) / 2;
   hipLaunchKernelGGL(randint_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, seed, stream_id, count, n, out);
   return check_launch("randint");
+}
+
+// Dataset._next_train for one image (nerf_sh/nerf/datasets.py:159-166) in ONE launch: the pixel ids of randint_kernel
+// (element i = 64-bit pair i % 2 of Philox block i / 2, mod W*H), the rays of generate_rays_kernel and the gather of the
+// image's colours -- the same arithmetic as the three separate launches, bit for bit.
+__global__ void sample_batch_kernel(uint64_t seed, uint64_t stream_id, const float* __restrict__ c2w, int W, int H, float focal,
+                                    const float* __restrict__ image, int64_t B, int64_t* __restrict__ ids,
+                                    float* __restrict__ o, float* __restrict__ d, float* __restrict__ v,
+                                    float* __restrict__ pixels) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int64_t q = i >> 1;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const int h = (int)(i & 1);
+  const uint64_t r64 = ((uint64_t)(h ? c[2] : c[0]) << 32) | (h ? c[3] : c[1]);
+  const int64_t p = (int64_t)(r64 % (uint64_t)((int64_t)W * H));
+  if (ids) ids[i] = p;
+  pixel_ray(c2w, W, H, focal, p, i, o, d, v);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) pixels[i * 3 + a] = image[p * 3 + a];
+}
+
+int launch_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal, const float* image,
+                        int64_t B, int64_t* ids, float* o, float* d, float* v, float* pixels, hipStream_t s) {
+  if (B == 0) return PXO_OK;
+  hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, seed, stream_id, c2w, W, H, focal,
+                     image, B, ids, o, d, v, pixels);
+  return check_launch("sample_batch");
 }
 
 int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s, const float* sq_x, int64_t sq_n,

@@ -97,6 +97,11 @@ class HipFeeder:
     def generate_rays_multi(self, c2w_all, w, h, focal, ray_ids):
         return self.ops.generate_rays_multi(c2w_all, w, h, focal, ray_ids)
 
+    def sample_batch(self, seed, draw, count, c2w, w, h, focal, image_rgb):
+        """randint + generate_rays + the gather of the image's colours in one launch (pxo_sample_batch): the same values as
+        the three calls above, bit for bit."""
+        return self.ops.sample_batch(seed, draw, c2w, w, h, focal, image_rgb, count)
+
 
 class Dataset:
     """Iterator yielding {"pixels": [B,3], "rays": Rays([B,3] x3)} on `device`."""
@@ -142,6 +147,11 @@ class Dataset:
             # datasets.py:159-166: one random image, batch_size random pixels (with replacement)
             image_index = int(self.rng.randint(0, self.n_examples))
             self.draws += 1
+            if getattr(self, "images", None) is not None and hasattr(self.feeder, "sample_batch"):
+                # resident images on the device: ids, rays and colours in one launch
+                o, d, v, px = self.feeder.sample_batch(self.seed, self.draws, self.batch_size, self._c2w_dev[image_index],
+                                                       self.w, self.h, self.focal, self.images[image_index])
+                return {"pixels": px, "rays": utils.Rays(o, d, v)}
             ray_indices = self.feeder.randint(self.seed, self.draws, self.batch_size, self.h * self.w)
             rays = self._rays_for(image_index, ray_indices)
             return {"pixels": self._pixels_for(image_index, ray_indices, rays), "rays": rays}

@@ -1134,3 +1134,38 @@ def test_skip_zero_rows_is_bit_identical(deg, shift, wd):
         assert 0 < l1 < 0.9 * t1, (l1, t1)                          # the case the option exists for (measured 0.32 / 0.84)
     else:
         assert l1 <= t1
+
+
+def test_sample_batch_equals_the_three_separate_launches():
+    """pxo_sample_batch (Dataset._next_train for one image in one launch) against pxo_randint + pxo_generate_rays + the gather
+    of the image's colours: bit for bit, odd batch size included; and through datasets.Synthetic, whose batches must not
+    change when the fused launch replaces the three."""
+    ops = _ops(); dev = _gpu()
+    from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
+    W, H, focal = 37, 29, 41.5
+    c2w = torch.from_numpy(pose_spherical(33.0, 20.0, 4.0)).to(dev)
+    image = torch.rand(H * W, 3, device=dev)
+    for B in (1, 777, 4096):
+        o, d, v, px, ids = ops.sample_batch(12345, 9, c2w, W, H, focal, image, B, want_ids=True)
+        want_ids = ops.randint(12345, 9, B, W * H, device=dev)
+        assert torch.equal(ids, want_ids)
+        o2, d2, v2 = ops.generate_rays(c2w, W, H, focal, want_ids)
+        assert torch.equal(o, o2) and torch.equal(d, d2) and torch.equal(v, v2)
+        assert torch.equal(px, image[want_ids])
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
+    utils.update_flags(args); args.factor = 16
+    fused = datasets.get_dataset("train", args, dev, batch_size=300)
+    plain = datasets.get_dataset("train", args, dev, batch_size=300)
+    class _NoFused:                       # the same feeder without the fused entry point
+        def __init__(self, f): self.f = f
+        def __getattr__(self, k):
+            if k == "sample_batch":
+                raise AttributeError(k)
+            return getattr(self.f, k)
+    plain.feeder = _NoFused(plain.feeder)
+    for _ in range(3):
+        a, b = next(fused), next(plain)
+        assert torch.equal(a["pixels"], b["pixels"])
+        for x, y in zip(a["rays"], b["rays"]):
+            assert torch.equal(x, y)

@@ -968,6 +968,20 @@ def test_error_paths_on_device():
                           torch.zeros(6, device=dev), torch.empty(1024, dtype=torch.uint8, device=dev))
     with pytest.raises(_lib.PxoError):
         ops.posenc(torch.zeros(4, 3))          # host tensor
+    # round-4 entry points: negative noise, an unknown profiling tag, a workspace too small for the work report,
+    # a configuration field out of range
+    with pytest.raises(_lib.PxoError, match="pxo_add_gaussian_noise"):
+        ops.add_gaussian_noise(torch.zeros(8, device=dev), -1.0)
+    with pytest.raises(_lib.PxoError, match="mask"):
+        _lib.check(_lib.load().pxo_profile_enable(1 << 7), "pxo_profile_enable")
+    with pytest.raises(_lib.PxoError, match="workspace"):
+        ops.train_backward_work(pcfg, 8, torch.empty(1024, dtype=torch.uint8, device=dev))
+    bad = pxo_cfg(ops, cfg); bad.skip_zero_rows = 2
+    with pytest.raises(_lib.PxoError, match="skip_zero_rows"):
+        ops.train_workspace_bytes(bad, 8)
+    bad = pxo_cfg(ops, cfg); bad.noise_std = -0.5
+    with pytest.raises(_lib.PxoError, match="noise_std"):
+        ops.train_workspace_bytes(bad, 8)
 
 
 def test_empty_inputs_are_accepted():
@@ -988,6 +1002,9 @@ def test_empty_inputs_are_accepted():
     assert ops.grid_sigma(pcfg, packed[1][0], 16, 5, 5, [0.0] * 3, [1.0] * 3).numel() == 0
     p = torch.zeros(0, device=dev)
     ops.adam_step(p, p.clone(), p.clone(), p.clone(), 1e-3, 1)
+    assert ops.add_gaussian_noise(p.clone(), 0.5, seed=3).numel() == 0
+    ob, db, vb, pxb = ops.sample_batch(1, 2, torch.eye(4, device=dev), 8, 8, 10.0, torch.zeros(64, 3, device=dev), 0)
+    assert ob.shape == (0, 3) and pxb.shape == (0, 3)
     torch.cuda.synchronize()
     from plenoctree_amd import _lib
     with pytest.raises(_lib.PxoError):                      # the train step needs at least one ray

@@ -717,12 +717,16 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 // backward (data): d_raw -> dz_7 .. dz_0
 // ------------------------------------------------------------------------------------------
 template <int NHB, int RBN, bool SKIP>
-__device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restrict__ db_slot, uint8_t* __restrict__ tile_live,
+__device__ __forceinline__ int bwd_tile(float* __restrict__ lds, float* __restrict__ db_slot, uint8_t* __restrict__ tile_live,
                                          const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
                                          const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask,
                                          int64_t M, int deg, int64_t row0, int64_t slot, float* __restrict__ dz,
                                          int* __restrict__ nz, uint8_t* __restrict__ chunk_live,
-                                         int tid, int lane, int wave) {
+                                         int tid, int lane, int wave, int mask_word0 = 0) {
+  // returns 0 when the tile is done (or skipped); in skipping mode a FULL tile whose live rows all sit in one 64-row half
+  // returns 1 (lower half) / 2 (upper half) without computing: the caller runs that half as a half-height tile (mask_word0
+  // = which of the slot's two mask words holds the half's bits).  The dead half adds exact zeros to the tile's bias column
+  // sums, in front of or behind the live half's terms, so the slot's partial keeps its bits.
   constexpr int NH = 32 * NHB;
   constexpr int kRows = 32 * RBN;
   constexpr int kWordsUsed = RBN * kCB * 16 / 32;
@@ -757,7 +761,14 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
     for (int c = 0; c < kChunks; ++c) any |= nz[c];
     if (tid < kChunks) chunk_live[row0 / kLiveRows + tid] = (uint8_t)nz[tid];
     if (tid == 0) *tile_live = (uint8_t)(any != 0);       // the reduction of the bias partials leaves dead slots out
-    if (!any) return;
+    if (!any) return 0;
+    if (RBN == kRB) {
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int c = 0; c < kChunks / 2; ++c) { lo |= nz[c]; hi |= nz[kChunks / 2 + c]; }
+      if (!hi) return 1;
+      if (!lo) return 2;
+    }
   } else if (tid == 0) {
     *tile_live = 1;
   }
@@ -774,7 +785,7 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
   zero_acc(acc);
   uint32_t mw[kMaskWords];   // relu-mask words of the layer whose gradient the running GEMM produces
   {
-    const uint32_t* mp = mask + ((slot * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords;
+    const uint32_t* mp = mask + ((slot * kDepth + (kDepth - 1)) * kMlpThreads + tid) * kMaskWords + mask_word0;
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];
     const int wp = (wave * kCB) * 64;      // wave-uniform f32x4 index into the image (head^T first)
@@ -810,12 +821,13 @@ __device__ __forceinline__ void bwd_tile(float* __restrict__ lds, float* __restr
     lds_barrier();
     if (l == 0) break;
     zero_acc(acc);
-    const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords;
+    const uint32_t* mp = mask + ((slot * kDepth + (l - 1)) * kMlpThreads + tid_e) * kMaskWords + mask_word0;
 #pragma unroll
     for (int w = 0; w < kWordsUsed; ++w) mw[w] = mp[w];     // next layer's mask, fetched under the GEMM
     const TileCopy tc = make_tile_copy<RBN>(lds, dz + (int64_t)l * M * kW, row0, M, wave, lane, true);
     gemm_lds_packed<RBN, kCB, true>(arow, wimg, wp, 32, 8 * 64, acc, bfrag, &tc);
   }
+  return 0;
 }
 
 template <int NHB, bool SKIP>
@@ -835,10 +847,13 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   const int64_t n_slots = ts.n_full + ts.n_half;
   auto run = [&](int64_t slot) {
     float* db = dbias_partial + slot * 9 * kW;
-    if (slot < ts.n_full)
-      bwd_tile<NHB, kRB, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg, slot * kTM, slot, dz, nz,
-                               chunk_live, tid, lane, wave);
-    else
+    if (slot < ts.n_full) {
+      const int half = bwd_tile<NHB, kRB, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
+                                                slot * kTM, slot, dz, nz, chunk_live, tid, lane, wave);
+      if (SKIP && half)
+        bwd_tile<NHB, kRB / 2, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
+                                     slot * kTM + (half - 1) * (kTM / 2), slot, dz, nz, chunk_live, tid, lane, wave, half - 1);
+    } else
       bwd_tile<NHB, kRB / 2, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
                              ts.half_row0 + (slot - ts.n_full) * (kTM / 2), slot, dz, nz, chunk_live, tid, lane, wave);
   };

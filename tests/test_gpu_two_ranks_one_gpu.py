@@ -49,12 +49,13 @@ def _problem():
     return cfg, flat, rays, px, rnd
 
 
-def _run(rank, world, comm, dev):
+def _run(rank, world, comm, dev, skip=0):
     from _helpers import pxo_cfg
     from plenoctree_amd import dist, ops
     from plenoctree_amd.nerf_sh.nerf import models, utils
     cfg, flat, rays, px, rnd = _problem()
     pcfg = pxo_cfg(ops, cfg)
+    pcfg.skip_zero_rows = skip
     model = models.NerfModel(pcfg)
     state = models.TrainState(pcfg, flat.clone().to(dev))
     reducer = dist.GradReducer(comm, dev) if world > 1 else None
@@ -76,7 +77,9 @@ def _worker(rank, world, port, outdir):
     comm = dist.init_from_env(backend="gloo")
     assert comm.world == world
     params, stats, grads = _run(rank, world, comm, torch.device("cuda", 0))
-    torch.save({"params": params, "stats": stats, "grads": grads}, os.path.join(outdir, f"rank{rank}.pt"))
+    p1, s1, g1 = _run(rank, world, comm, torch.device("cuda", 0), skip=1)      # the CLI's default reverse pass
+    torch.save({"params": params, "stats": stats, "grads": grads, "params_skip": p1, "stats_skip": s1, "grads_skip": g1},
+               os.path.join(outdir, f"rank{rank}.pt"))
     comm.barrier()
     comm.shutdown()
 
@@ -90,6 +93,10 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step():
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     assert torch.equal(res[0]["params"], res[1]["params"]) and torch.equal(res[0]["stats"], res[1]["stats"])
     assert torch.equal(res[0]["grads"], res[1]["grads"])
+    # ... and the zero-row skipping reverse pass (each rank with its own live flags) leaves every bit where it was
+    for r in res:
+        assert torch.equal(r["params_skip"], r["params"]) and torch.equal(r["stats_skip"], r["stats"])
+        assert torch.equal(r["grads_skip"], r["grads"])
     single_p, single_s, single_g = _run(0, 1, dist.Comm(), torch.device("cuda", 0))
     # last step's gradient: mean over the two shards' gradients vs the full-batch gradient.  The ray terms are means over B
     # rays either way; the sparsity and weight-decay terms are identical on both ranks (same points, same parameters)

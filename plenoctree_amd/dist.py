@@ -110,15 +110,18 @@ class GradReducer:
         with torch.cuda.stream(self.side):
             self.event.wait(self.side)              # ... and nothing else of this step
             w0 = self._reduce(bucket0, True)
-            if w0 is not None:
-                w0.wait()                           # side stream ordered after the collective
-            done0 = torch.cuda.Event(enable_timing=self.record_timing)
-            done0.record(self.side)
+            if self.record_timing:                  # tests: when was bucket 0 done, on the device's clock
+                if w0 is not None:
+                    w0.wait()
+                self.bucket0_done = torch.cuda.Event(enable_timing=True)
+                self.bucket0_done.record(self.side)
         w1 = self._reduce(bucket1, True)            # ordered after everything queued on the current stream
+        # the caller's stream waits for both collectives directly (Work.wait orders the CURRENT stream behind the work):
+        # no event hop through the side stream on the way back
+        if w0 is not None:
+            w0.wait()
         if w1 is not None:
             w1.wait()
-        torch.cuda.current_stream().wait_event(done0)
-        self.bucket0_done = done0                   # tests time it against the end of the step's kernels
 
 
 def init_from_env(backend=None, device=None):

@@ -210,7 +210,7 @@ class Job:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29533 + os.getpid() % 2000))
-        kw = {"device_id": self.device} if self.a.backend == "nccl" else {}
+        kw = {"device_id": self.device, "pg_options": self.pdist.nccl_options()} if self.a.backend == "nccl" else {}
         dist_mod.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)   # "nccl" = RCCL over xGMI
         self.dist = dist_mod
 

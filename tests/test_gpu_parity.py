@@ -1067,7 +1067,7 @@ def test_bucketed_gradient_exchange_rides_under_the_fine_level():
     if own:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=pdist.nccl_options())
     try:
         cfg = O.Cfg(sparsity_npoints=1000, weight_decay_mult=0.1)
         pcfg = pxo_cfg(ops, cfg)

@@ -200,8 +200,14 @@ class Job:
         self.dist = None
         self.ranks_seen = 1
         self.pdist = pdist
-        if self.world > 1 or a.force_dist:
+        self.exchange = self.world > 1 or a.force_dist       # do the legs other than strong512 exchange gradients?
+        want_strong = self.cuda and not a.no_extras and "strong512" in a.extras.split(",")
+        if self.exchange or want_strong:
+            # the group (and with it RCCL's high-priority stream) is created BEFORE any kernel runs: created after the
+            # headline leg, the same stream made the 512-ray step 26 % slower (4.55 vs 3.60 ms, profiles/r04h_late_group.txt)
             self.init_group()
+            if self.cuda:
+                self.pdist.exchange_stream(self.device)
             one = torch.ones(1, device=self.device)
             self.dist.all_reduce(one)
             self.ranks_seen = int(one.item())
@@ -214,9 +220,11 @@ class Job:
         dist_mod.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)   # "nccl" = RCCL over xGMI
         self.dist = dist_mod
 
-    def reducer(self):
-        """The per-step gradient exchange (two buckets, dist.GradReducer); forced on for one rank when a group exists."""
-        return self.pdist.GradReducer(self.comm(), self.device, force=self.dist is not None)
+    def reducer(self, force=None):
+        """The per-step gradient exchange (two buckets, dist.GradReducer): on with more than one rank or --force-dist, and in
+        the strong512 leg (`force=True`: through RCCL even with one rank)."""
+        force = self.exchange if force is None else force
+        return self.pdist.GradReducer(self.comm(), self.device, force=bool(force) and self.dist is not None)
 
     def sync(self):
         if self.dist:
@@ -254,7 +262,7 @@ def read_kernels(ops, deg):
     return kernels
 
 
-def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, events=True, **flag_over):
+def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, events=True, exchange=None, **flag_over):
     """W untimed + K timed train steps of `preset`; returns a dict with elapsed (max over ranks), kernels, stats.
     snapshot_step: a copy of the parameters after exactly that many steps from the fixed-seed initialisation is kept
     (taken inside the run if it gets that far, by untimed extra steps otherwise), so that the records evaluated on
@@ -268,7 +276,7 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, even
     model, params = models.construct_nerf(args, job.device)
     state = models.TrainState(model.cfg, params)
     dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
-    reducer = job.reducer()
+    reducer = job.reducer(exchange)
     snap = {}
 
     def one_step(step):
@@ -386,27 +394,19 @@ def run_strong(job, a):
     rays per GPU per step (train.py:117-118: pmean per step).  Measured on this job's GPUs with 512 rays each and
     the per-step collectives issued through RCCL even with one rank (two buckets, dist.GradReducer), so the number is
     what one GPU of an 8-GPU strong-scaling run does before the wire time of the exchange."""
-    own_group, err = False, None
-    if job.dist is None:
-        try:
-            job.init_group()
-            own_group = True
-        except Exception as e:                       # the record then says so instead of failing the bench
-            err = repr(e)[:200]
+    err = None
+    if job.dist is None:                              # (the group is created in Job.__init__ whenever this leg is wanted)
+        err = "no process group"
     rays = a.strong_rays
     k = max(40, a.steps) if job.cuda else a.steps
-    t = run_train(job, a.preset, k, 5 if job.cuda else 1, per_gpu=rays)
+    t = run_train(job, a.preset, k, 5 if job.cuda else 1, per_gpu=rays, exchange=True)
     rec = {"value": rays * job.world * k / t["elapsed"], "unit": "rays/s", "rays_per_gpu": rays, "steps": k,
            "ms_per_step": 1e3 * t["elapsed"] / k, "collectives_per_step": t["collectives_per_step"],
            "frac": rays * k / t["elapsed"] * FLOP_TRAIN_PER_RAY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12),
            "kernels": [{"kernel": e["kernel"], "avg_ms": e["avg_ms"], "tflops": e.get("tflops")} for e in t["kernels"]],
            "note": "per-GPU work of the 8-GPU strong-scaling run of the reference's 4096-ray batch; 10k sparsity points "
                    "per GPU per step (train.py:78-80) are not counted as rays"}
-    if own_group:
-        job.sync()
-        job.dist.destroy_process_group()
-        job.dist = None
-    elif err:
+    if err:
         rec["rccl_init_error"] = err
     return rec
 
@@ -605,7 +605,7 @@ def main(argv=None):
                                    "800x800 synthetic views, sparsity 10k pts, Adam",
                        "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
                        "parallelism": f"dp{world}"},
-            "nccl_ranks_seen": job.ranks_seen, "collectives_per_step": head["collectives_per_step"],
+            "nccl_ranks_seen": job.ranks_seen if (job.exchange or world > 1) else 1, "collectives_per_step": head["collectives_per_step"],
             "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
             "final_stats": head["stats"],
             "roofline": roofline, "kernels": kernels,

@@ -65,6 +65,19 @@ class Comm:
             torch.distributed.destroy_process_group()
 
 
+_SIDE_STREAMS = {}
+
+
+def exchange_stream(device, priority=-1):
+    """The high-priority stream the gradient exchange hangs its first bucket on; one per device and priority, created once
+    (bench.py creates it together with the process group, before any kernel runs: created later, after seconds of compute,
+    the same stream cost the 512-ray step 2 %, profiles/r04h_late_group.txt)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), priority)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return _SIDE_STREAMS[key]
+
+
 class GradReducer:
     """lax.pmean(grad) + lax.pmean(stats) (nerf_sh/train.py:117-118) as TWO sum-all-reduces per step instead of one
     after the backward pass: MLP_0's half of the gradient arena is final once the coarse level has been reversed -- a
@@ -91,7 +104,7 @@ class GradReducer:
             # hardware queues, and a collective whose queue also carries the step's kernels is dispatched behind all of
             # them -- measured (scripts/overlap_probe.py, profiles/r04h_overlap_probe.txt): with normal-priority streams
             # bucket 0 is done 0.03 ms AFTER the step's last kernel, with high-priority ones 9.1 ms BEFORE it (2048 rays)
-            self.side = torch.cuda.Stream(device=device, priority=side_priority)
+            self.side = exchange_stream(device, side_priority)
 
     def ready_event(self):
         """What pxo_train_fwd_bwd_bucketed records when bucket 0 is final (None: no overlap, e.g. on the CPU)."""
@@ -149,6 +162,8 @@ def init_from_env(backend=None, device=None):
         if backend == "nccl":
             kw["pg_options"] = nccl_options()
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if backend == "nccl" and torch.cuda.is_available():
+            exchange_stream(torch.device("cuda", local_rank))     # early, see exchange_stream
     return Comm(world, rank, local_rank, backend)
 
 

@@ -51,7 +51,11 @@ def main(argv=None):
 
     reducer = dist.GradReducer(comm, device)
     t_loop_start = time.time()
-    stats_trace, loss_trace = [], []
+    stats_trace = []
+    # the reference averages loss / psnr over EVERY step since the last print (stats_trace, train.py:199-200,216-218); here the
+    # sum lives on the device (one 6-float add per step) so that the host never waits for a step it does not print
+    stats_acc = torch.zeros(6, dtype=torch.float64, device=device)
+    acc_steps = 0
     reset_timer = True
     for step in range(init_step, args.max_steps + 1):
         if reset_timer:
@@ -63,21 +67,23 @@ def main(argv=None):
                                        args.lr_delay_mult)
         models.train_step(model, state, batch, lr, randomized=args.randomized, seed=(step << 8) | comm.rank,
                           world_size=comm.world, reducer=reducer)
+        stats_acc.add_(state.stats)
+        acc_steps += 1
         if step % args.print_every == 0:                            # train.py:208-236
             torch.cuda.synchronize()
             s = utils.Stats(*state.stats.cpu().tolist())
-            # the reference averages the loss of every step since the last print (stats_trace, train.py:199-200,216-218);
-            # reading the device every step would serialise host and GPU, so the average here is over the printed steps
-            loss_trace.append(s.loss)
+            avg = utils.Stats(*(stats_acc / max(acc_steps, 1)).cpu().tolist())
+            stats_acc.zero_()
+            acc_steps = 0
             steps_per_sec = args.print_every / (time.time() - t_loop_start)
             reset_timer = True
             rays_per_sec = args.batch_size * steps_per_sec          # train.py:224
             if h0:
                 precision = int(np.ceil(np.log10(args.max_steps))) + 1
                 print(("{:" + "{:d}".format(precision) + "d}").format(step) + f"/{args.max_steps:d}: "
-                      + f"i_loss={s.loss:0.4f}, avg_loss={float(np.mean(loss_trace[-8:])):0.4f}, weight_l2={s.weight_l2:0.2e}, lr={lr:0.2e}, "
+                      + f"i_loss={s.loss:0.4f}, avg_loss={avg.loss:0.4f}, weight_l2={s.weight_l2:0.2e}, lr={lr:0.2e}, "
                       + f"{rays_per_sec:0.0f} rays/sec", flush=True)
-                stats_trace.append((step, s.loss, s.psnr, rays_per_sec))
+                stats_trace.append((step, s.loss, s.psnr, rays_per_sec, avg.loss, avg.psnr))
         if step % args.save_every == 0 and h0:                      # train.py:237-242
             checkpoints.save_checkpoint(args.train_dir, state, step, keep=200)
         if args.render_every > 0 and step % args.render_every == 0:  # train.py:245-296 (PSNR only)

@@ -708,7 +708,13 @@ def test_cli_train_eval_extraction(tmp_path):
                 "save_every: 60\nrender_every: 0\n")
     common = ["--train_dir", str(tmp_path), "--config", cfg_path]
     trace = train.main(common)
-    assert len(trace) == 3 and trace[-1][1] < trace[0][1], trace          # (step, loss, psnr, rays/s)
+    assert len(trace) == 3 and trace[-1][1] < trace[0][1], trace          # (step, loss, psnr, rays/s, avg_loss, avg_psnr)
+    # avg_loss / avg_psnr = means over EVERY step since the last print (train.py:216-218), accumulated on the device: of the
+    # size of the per-step values (batches of different images are noisy), falling from window to window, and consistent with
+    # each other (mean psnr >= psnr of the mean loss, within a dB at this noise level)
+    for (_, loss, _, _, avg_loss, avg_psnr) in trace:
+        assert 0.5 * loss < avg_loss < 2.0 * loss and 0.0 <= avg_psnr + 10.0 * np.log10(avg_loss) < 1.0, trace
+    assert trace[-1][4] < trace[0][4], trace
     assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_60"))
     psnrs = eval_mod.main(common + ["--approx_eval_skip", "100", "--chunk", "4096", "--save_output", "false"])   # 2 images of 200x200
     assert len(psnrs) == 2 and all(np.isfinite(psnrs)) and min(psnrs) > 5.0

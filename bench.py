@@ -58,6 +58,8 @@ def parse(argv=None):
                         "multi-GPU code path on a 1-GPU box)")
     p.add_argument("--no-kernel-events", action="store_true",
                    help="A/B only: no HIP events around the dominant kernels in the timed region (no roofline leg)")
+    p.add_argument("--tune", default="", help="A/B only: pxo_set_tuning knobs, e.g. tile_sched=1,wgrad_ranges=73,wgrad_skinny_ranges=128 "
+                                              "(same results, different schedule; recorded in the line as `tuning`)")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
     p.add_argument("--cpu-steps", type=int, default=8)
     p.add_argument("--converge-steps", type=int, default=2000, help="training budget of the `converge` record")
@@ -532,6 +534,19 @@ def main(argv=None):
         if job.dist:
             job.dist.barrier()
 
+    tuning = {}
+    if a.tune:
+        from plenoctree_amd import ops
+        knobs = {"tile_sched": ops.TUNE_TILE_SCHED, "wgrad_ranges": ops.TUNE_WGRAD_RANGES,
+                 "wgrad_skinny_ranges": ops.TUNE_WGRAD_SKINNY_RANGES}
+        for kv in a.tune.split(","):
+            k, _, v = kv.partition("=")
+            if k not in knobs:
+                raise SystemExit(f"bench.py --tune: unknown knob {k!r} (have {sorted(knobs)})")
+            if job.cuda:
+                ops.set_tuning(knobs[k], int(v))
+            tuning[k] = int(v)
+
     want = [] if a.no_extras else [e for e in a.extras.split(",") if e]
     unknown = [e for e in want if e not in ALL_EXTRAS]
     if unknown:
@@ -610,6 +625,8 @@ def main(argv=None):
             "final_stats": head["stats"],
             "roofline": roofline, "kernels": kernels,
         }
+        if tuning:
+            out["tuning"] = tuning
         if "converge" in extras:
             out["eval_psnr"] = extras["converge"]["eval_psnr"]      # the metric's second half, next to `value`
         out.update(extras)

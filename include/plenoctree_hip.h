@@ -89,8 +89,14 @@ typedef struct PxoLeaf {
   int32_t cols;       /* kernel: out; bias: 1   */
 } PxoLeaf;
 
+/* ABI version of this header: bumped whenever a struct gains a field or an entry point changes meaning (5: PxoCfg has
+ * noise_std + skip_zero_rows, pxo_profile_enable takes a tag MASK, pxo_set_tuning / pxo_occupy_cus exist).  A binding checks
+ * pxo_version() == PXO_ABI_VERSION and pxo_cfg_bytes() == sizeof(PxoCfg) after dlopen (plenoctree_amd/_lib.py does): a
+ * caller built against an older header would otherwise pass a short PxoCfg and have its tail read from past the end. */
+#define PXO_ABI_VERSION 5
 const char* pxo_last_error(void);
 int pxo_version(void);
+size_t pxo_cfg_bytes(void);
 /* Rows (samples) per tile of the fused MLP kernels in this build (64 or 128); informational. */
 int pxo_tile_rows(void);
 
@@ -302,7 +308,28 @@ int pxo_eval_points(const PxoCfg* cfg, const float* packed_fwd, const float* poi
 int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
 
+/* ---- run-time choices between implementations of the same result ----------------------- */
+/* Process-wide; results are bit-identical either way (tests/test_gpu_parity.py), only the time differs.  Used by A/B
+ * sessions (bench.py --tune) and equality tests; nothing is read from the environment.
+ *   PXO_TUNE_TILE_SCHED    how the persistent workgroups of the dense training kernels (mlp_fwd with saved tensors,
+ *                          mlp_bwd_data) pick their 128-row tiles inside pxo_train_fwd_bwd*: 0 = static stride,
+ *                          1 = from a device counter, so that a workgroup that starts late -- because a collective's
+ *                          kernel held its CU at the launch boundary -- is not the launch's tail.  (The zero-row skipping
+ *                          backward always uses the counter.)
+ *   PXO_TUNE_WGRAD_RANGES  row ranges (split-K slabs) per layer of the 256x256 weight-gradient products: 0 = built-in
+ *                          choice by pass size, n = exactly n (1 .. number of CUs). */
+#define PXO_TUNE_TILE_SCHED 0
+#define PXO_TUNE_WGRAD_SKINNY_RANGES 2   /* the same for the two skinny products (enc-based pair, heads): 1 .. 2 x number of CUs */
+#define PXO_TUNE_WGRAD_RANGES 1
+int pxo_set_tuning(int knob, int value);
+int pxo_get_tuning(int knob, int* value);
+
 /* ---- measurement ------------------------------------------------------------------ */
+/* Diagnostic for contention probes (scripts/contention_probe.py): `blocks` workgroups of `threads` threads that idle for
+ * `micros` microseconds of the device's constant-rate clock on `stream` -- what the kernel of a ring all-reduce looks like to
+ * the kernels it shares the GPU with (it occupies CU slots and moves no data).  No reference counterpart. */
+int pxo_occupy_cus(int blocks, int threads, float micros, void* stream);
+
 /* HIP-event timing of the dominant kernels on the stream they are launched on (bench.py's
  * roofline leg; the reference only has wall-clock rays/sec, nerf_sh/train.py:222-226).
  * Tags: 0 mlp_fwd, 1 mlp_bwd_data, 2 wgrad 256x256 GEMM, 3 other wgrad GEMMs.

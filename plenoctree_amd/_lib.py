@@ -70,6 +70,7 @@ class PxoCamera(Structure):
 
 
 TREE_MAX_DEPTH = 10
+ABI_VERSION = 5                     # PXO_ABI_VERSION of include/plenoctree_hip.h
 
 P = c_void_p
 CFG = POINTER(PxoCfg)
@@ -79,6 +80,10 @@ F3 = POINTER(c_float)
 SIGNATURES = {
     "pxo_last_error": (c_char_p, []),
     "pxo_version": (c_int, []),
+    "pxo_cfg_bytes": (c_size_t, []),
+    "pxo_set_tuning": (c_int, [c_int, c_int]),
+    "pxo_get_tuning": (c_int, [c_int, POINTER(c_int)]),
+    "pxo_occupy_cus": (c_int, [c_int, c_int, c_float, P]),
     "pxo_tile_rows": (c_int, []),
     "pxo_param_layout": (c_int, [CFG, POINTER(PxoLeaf), POINTER(c_int64)]),
     "pxo_packed_sizes": (c_int, [CFG, POINTER(c_int64), POINTER(c_int64)]),
@@ -174,6 +179,11 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    # the struct layouts of this module are those of include/plenoctree_hip.h at ABI_VERSION: a stale library (or a stale
+    # copy of this file) would pass a short PxoCfg and have its tail read from past the end
+    if lib.pxo_version() != ABI_VERSION or lib.pxo_cfg_bytes() != ctypes.sizeof(PxoCfg):
+        raise PxoError(f"{path}: ABI version {lib.pxo_version()} / sizeof(PxoCfg) {lib.pxo_cfg_bytes()}, this binding expects "
+                       f"{ABI_VERSION} / {ctypes.sizeof(PxoCfg)}: rebuild with `python -m plenoctree_amd.build`")
     _lib = lib
     return lib
 

@@ -18,8 +18,8 @@
 //    that one ds_read_b128 / one 16 B global load feeds four consecutive MFMAs;
 //  * post-ReLU activations are streamed to HBM once (for the weight-gradient GEMMs) as whole
 //    1 KiB rows copied out of the LDS tile, together with a 1-bit relu mask in fragment order, so
-//    the backward-data kernel never re-reads them; bias gradients accumulate in LDS across a
-//    workgroup's tiles (one owner thread per element) and leave as one partial per workgroup.
+//    the backward-data kernel never re-reads them; bias gradients leave as one [9][256] partial per tile slot
+//    (schedule-independent bits; summed in a fixed order by reduce_jobs_kernel).
 #include "pxo_common.h"
 
 namespace pxo {
@@ -634,20 +634,59 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
   }
 }
 
-template <int NHB, bool SAVE, bool RGB>
+// Tile schedules of the persistent workgroups (both kernels of this file):
+//   static  (DYN = false)  workgroup b runs slots b, b + grid, b + 2 grid, ...
+//   dynamic (DYN = true)   workgroup b runs slot b first and then TAKES slots from a device counter (zero at launch):
+//                          slot = grid + atomicAdd(counter, 1).  The ticket for the NEXT slot is drawn by thread 0 when a
+//                          tile starts and lands in LDS long before the tile ends (a tile is ~200 us, the atomic ~2 us), so
+//                          the schedule costs two LDS barriers per tile.
+// Results do not depend on the schedule: a slot's rows, relu-mask words and bias partial are a function of the slot alone.
+// Why dynamic: with one 8-wave workgroup per CU at the full register / LDS budget nothing else can be co-resident, so a
+// collective's kernel on the high-priority exchange stream (dist.GradReducer) takes whole CUs when it starts at a kernel
+// boundary; under the static stride the workgroups that start late on those CUs become the launch's tail, under the counter
+// their share is absorbed by all the others (scripts/contention_probe.py).  Skipping mode (bwd) needs it for load balance.
+struct TileTicket {
+  int* next;                       // LDS word
+  unsigned int* counter;           // device word, zero when the launch starts
+  __device__ __forceinline__ void draw(int tid) const {
+    if (tid == 0) *next = (int)gridDim.x + (int)atomicAdd(counter, 1u);
+  }
+  __device__ __forceinline__ int64_t take() const {
+    lds_barrier();                 // thread 0's ticket is in LDS (and every wave is through the tile)
+    const int v = __builtin_amdgcn_readfirstlane(*next);
+    lds_barrier();                 // everyone has read it before thread 0 overwrites it
+    return v;
+  }
+};
+
+template <int NHB, bool SAVE, bool RGB, bool DYN = false>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_fwd_kernel(
     const float* __restrict__ pk, const float* __restrict__ pts, GridSpec grid, int64_t M, int deg, TileSched ts,
     float* __restrict__ raw_rgb, float* __restrict__ raw_sigma, float* __restrict__ acts,
-    float* __restrict__ enc_out, uint32_t* __restrict__ mask) {
-  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA];
+    float* __restrict__ enc_out, uint32_t* __restrict__ mask, unsigned int* __restrict__ tile_counter) {
+  __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + (DYN ? 4 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)
-    fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,
-                                  mask, tid, lane, wave);
-  for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
-    fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + h * (kTM / 2), ts.n_full + h,
-                                      raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);
+  if (!DYN) {
+    for (int64_t tile = blockIdx.x; tile < ts.n_full; tile += gridDim.x)
+      fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, tile * kTM, tile, raw_rgb, raw_sigma, acts, enc_out,
+                                    mask, tid, lane, wave);
+    for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x)
+      fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + h * (kTM / 2), ts.n_full + h,
+                                        raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);
+  } else {
+    const TileTicket tk{reinterpret_cast<int*>(lds + kTM * kLDA), tile_counter};
+    const int64_t n_slots = ts.n_full + ts.n_half;
+    for (int64_t slot = blockIdx.x; slot < n_slots; slot = tk.take()) {
+      tk.draw(tid);
+      if (slot < ts.n_full)
+        fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, slot * kTM, slot, raw_rgb, raw_sigma, acts, enc_out,
+                                      mask, tid, lane, wave);
+      else
+        fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + (slot - ts.n_full) * (kTM / 2), slot,
+                                          raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);
+    }
+  }
 }
 
 static unsigned mlp_grid(int64_t M) {
@@ -658,39 +697,44 @@ static unsigned mlp_grid(int64_t M) {
 template <int NHB>
 static int launch_fwd_nhb(const PxoCfg* cfg, const float* pk, const float* pts, const GridSpec& grid,
                           int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
-                          uint32_t* mask, hipStream_t s) {
+                          uint32_t* mask, unsigned int* tile_counter, hipStream_t s) {
   KernelTimer timer(PXO_PROF_MLP_FWD, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
   const TileSched ts = tile_sched(M, grid_dim.x);
-  if (acts && raw_rgb)
+  // the training instantiations (saved tensors) take their tiles from `tile_counter` when the caller provides one
+  // (pre-zeroed, see launch_uniform_jobs); the forward-only ones keep the static stride
+  if (acts && raw_rgb && tile_counter)
+    hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, true, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
+                       raw_rgb, raw_sigma, acts, enc, mask, tile_counter);
+  else if (acts && raw_rgb)
     hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+                       raw_rgb, raw_sigma, acts, enc, mask, tile_counter);
   else if (acts)
     hipLaunchKernelGGL((mlp_fwd_kernel<NHB, true, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+                       raw_rgb, raw_sigma, acts, enc, mask, tile_counter);
   else if (raw_rgb)
     hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, true>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+                       raw_rgb, raw_sigma, acts, enc, mask, tile_counter);
   else
     hipLaunchKernelGGL((mlp_fwd_kernel<NHB, false, false>), grid_dim, block, 0, s, pk, pts, grid, M, cfg->sh_deg, ts,
-                       raw_rgb, raw_sigma, acts, enc, mask);
+                       raw_rgb, raw_sigma, acts, enc, mask, tile_counter);
   return check_launch("mlp_fwd");
 }
 
 static int launch_fwd_any(const PxoCfg* cfg, const float* pk, const float* pts, const GridSpec& grid,
                           int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
-                          uint32_t* mask, hipStream_t s) {
+                          uint32_t* mask, unsigned int* tile_counter, hipStream_t s) {
   if (M == 0) return PXO_OK;
   switch (head_blocks(cfg->sh_deg)) {
-    case 1: return launch_fwd_nhb<1>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, s);
-    case 2: return launch_fwd_nhb<2>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, s);
-    default: return launch_fwd_nhb<3>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, s);
+    case 1: return launch_fwd_nhb<1>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, tile_counter, s);
+    case 2: return launch_fwd_nhb<2>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, tile_counter, s);
+    default: return launch_fwd_nhb<3>(cfg, pk, pts, grid, M, raw_rgb, raw_sigma, acts, enc, mask, tile_counter, s);
   }
 }
 
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
                    float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
-                   hipStream_t s) {
+                   hipStream_t s, unsigned int* tile_counter) {
   if (cfg->mlp_precision == PXO_MLP_BF16X3) {
     if (acts || enc || mask) { set_error("mlp_fwd: mlp_precision bf16x3 is inference-only (no saved tensors)"); return PXO_ERR_UNSUPPORTED; }
     return launch_mlp_fwd_x3(cfg, packed_fwd, pts, 0, 0, nullptr, nullptr, M, raw_rgb, raw_sigma, s);
@@ -698,7 +742,7 @@ int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts,
   GridSpec g;
   g.enabled = 0; g.reso = 1; g.x0 = 0;
   for (int i = 0; i < 3; ++i) { g.off[i] = 0.f; g.scale[i] = 1.f; }
-  return launch_fwd_any(cfg, packed_fwd, pts, g, M, raw_rgb, raw_sigma, acts, enc, mask, s);
+  return launch_fwd_any(cfg, packed_fwd, pts, g, M, raw_rgb, raw_sigma, acts, enc, mask, tile_counter, s);
 }
 
 int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
@@ -710,7 +754,7 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
   g.enabled = 1; g.reso = reso; g.x0 = x0;
   for (int i = 0; i < 3; ++i) { g.off[i] = off[i]; g.scale[i] = scale[i]; }
   const int64_t M = (int64_t)(x1 - x0) * reso * reso;
-  return launch_fwd_any(cfg, packed_fwd, nullptr, g, M, nullptr, sigma_out, nullptr, nullptr, nullptr, s);
+  return launch_fwd_any(cfg, packed_fwd, nullptr, g, M, nullptr, sigma_out, nullptr, nullptr, nullptr, nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -830,7 +874,7 @@ __device__ __forceinline__ int bwd_tile(float* __restrict__ lds, float* __restri
   return 0;
 }
 
-template <int NHB, bool SKIP>
+template <int NHB, bool SKIP, bool DYN>
 __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_bwd_data_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb,
     const float* __restrict__ d_raw_sigma, const uint32_t* __restrict__ mask, int64_t M, int deg, TileSched ts,
@@ -840,7 +884,6 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   // reduce_jobs_kernel): a tile's sums are the same whichever workgroup computes it, so the schedule below is free
   __shared__ __attribute__((aligned(16))) float lds[kTM * kLDA + kTM / kLiveRows + 4];
   int* __restrict__ nz = reinterpret_cast<int*>(lds + kTM * kLDA);
-  int* __restrict__ next = nz + kTM / kLiveRows;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint8_t* const tile_live = reinterpret_cast<uint8_t*>(dbias_partial + mask_slots(M) * 9 * kW);
@@ -857,19 +900,16 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
       bwd_tile<NHB, kRB / 2, SKIP>(lds, db, tile_live + slot, pkb, d_raw_rgb, d_raw_sigma, mask, M, deg,
                              ts.half_row0 + (slot - ts.n_full) * (kTM / 2), slot, dz, nz, chunk_live, tid, lane, wave);
   };
-  if (!SKIP || tile_counter == nullptr) {
+  if (!DYN) {
     for (int64_t slot = blockIdx.x; slot < ts.n_full; slot += gridDim.x) run(slot);
     for (int64_t h = blockIdx.x; h < ts.n_half; h += gridDim.x) run(ts.n_full + h);
   } else {
-    // skipping mode: a skipped tile costs ~1 % of a live one, so a static stride would leave the workgroups that drew
-    // few live tiles idle (measured: the kernel at 0.60 of its dense time with 13 % of the rows live); tiles are taken
-    // from a counter instead.  Results do not depend on the order (per-slot partials, disjoint dz rows).
-    for (;;) {
-      lds_barrier();
-      if (tid == 0) *next = (int)atomicAdd(tile_counter, 1u);
-      lds_barrier();
-      const int64_t slot = *next;
-      if (slot >= n_slots) break;
+    // tiles taken from the device counter (TileTicket above).  In skipping mode a skipped tile costs ~1 % of a live one, so
+    // the static stride would leave the workgroups that drew few live tiles idle (measured: the kernel at 0.60 of its dense
+    // time with 13 % of the rows live).  Results do not depend on the order (per-slot partials, disjoint dz rows).
+    const TileTicket tk{nz + kTM / kLiveRows, tile_counter};
+    for (int64_t slot = blockIdx.x; slot < n_slots; slot = tk.take()) {
+      tk.draw(tid);
       run(slot);
     }
   }
@@ -882,23 +922,25 @@ int mlp_bwd_partials(int64_t M) {
 
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
-                        float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s) {
+                        float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s,
+                        bool counter_is_zero) {
   if (M == 0) return PXO_OK;
-  if (tile_counter && hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), s) != hipSuccess) {
+  if (tile_counter && !counter_is_zero && hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), s) != hipSuccess) {
     set_error("mlp_bwd_data: hipMemsetAsync(tile counter) failed");
     return PXO_ERR_HIP;
   }
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
   const TileSched ts = tile_sched(M, grid_dim.x);
-#define PXO_BWD(NHB_)                                                                                                   \
-  do {                                                                                                                   \
-    if (chunk_live)                                                                                                      \
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB_, true>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,   \
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);                         \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB_, false>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma,  \
-                         mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter);                         \
+#define PXO_BWD_(NHB_, SKIP_, DYN_)                                                                                       \
+  hipLaunchKernelGGL((mlp_bwd_data_kernel<NHB_, SKIP_, DYN_>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma, \
+                     mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter)
+#define PXO_BWD(NHB_)                                                       \
+  do {                                                                      \
+    if (chunk_live && tile_counter) PXO_BWD_(NHB_, true, true);             \
+    else if (chunk_live) PXO_BWD_(NHB_, true, false);                       \
+    else if (tile_counter) PXO_BWD_(NHB_, false, true);                     \
+    else PXO_BWD_(NHB_, false, false);                                      \
   } while (0)
   switch (head_blocks(cfg->sh_deg)) {
     case 1: PXO_BWD(1); break;
@@ -906,6 +948,7 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
     default: PXO_BWD(3); break;
   }
 #undef PXO_BWD
+#undef PXO_BWD_
   return check_launch("mlp_bwd_data");
 }
 

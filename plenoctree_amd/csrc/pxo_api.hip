@@ -43,6 +43,14 @@ int num_cus() {
   return n;
 }
 
+// run-time choices between implementations of the same result (pxo_set_tuning)
+static int g_tune_tile_sched = 0;
+static int g_tune_wgrad_ranges = 0;
+static int g_tune_wgrad_skinny_ranges = 0;
+int tune_tile_sched() { return g_tune_tile_sched; }
+int tune_wgrad_ranges() { return g_tune_wgrad_ranges; }
+int tune_wgrad_skinny_ranges() { return g_tune_wgrad_skinny_ranges; }
+
 int validate_cfg(const PxoCfg* cfg) {
   PXO_REQUIRE(cfg != nullptr, "cfg is NULL");
   PXO_REQUIRE(cfg->sh_deg >= 0 && cfg->sh_deg <= 4, "sh_deg %d not in [0,4] (nerf_sh/nerf/sh.py:69)", cfg->sh_deg);
@@ -181,7 +189,8 @@ struct Draws { const float* t_rand; const float* u; bool noisy; uint64_t seed; }
 // every uniform draw of the step in one launch (jax.random.uniform call sites model_utils.py:135,262, train.py:79)
 static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomized, const float* t_rand, const float* u,
                          const float* sp_points, uint64_t seed, hipStream_t s, Draws& out, const float* params = nullptr,
-                         int64_t n_params = 0, float* sumsq_partial = nullptr) {
+                         int64_t n_params = 0, float* sumsq_partial = nullptr, unsigned int* zero_words = nullptr,
+                         int n_zero = 0) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PassBuffers& last = Nf > 0 ? t.f : t.c;
   UniformJob jobs[3];
@@ -203,15 +212,15 @@ static int prepare_draws(const PxoCfg* cfg, TrainWs& t, int64_t B, int randomize
   out.t_rand = t_rand; out.u = u;
   out.noisy = randomized != 0 && cfg->noise_std > 0.f;     // (noise_std is not None) and randomized, model_utils.py:329
   out.seed = seed;
-  return launch_uniform_jobs(seed, jobs, nj, s, params, n_params, sumsq_partial);
+  return launch_uniform_jobs(seed, jobs, nj, s, params, n_params, sumsq_partial, zero_words, n_zero);
 }
 
 static int forward_coarse(const PxoCfg* cfg, TrainWs& t, const float* pk0, const float* o, const float* d, const float* v,
                           int64_t B, const Draws& dr, const float* pixels, float* rgb_c, float* disp_c, float* acc_c,
-                          hipStream_t s) {
+                          hipStream_t s, unsigned int* tile_counter = nullptr) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PXO_TRY(launch_sample_along_rays(o, d, B, Nc, cfg->near_, cfg->far_, cfg->lindisp, dr.t_rand, t.c.z, t.c.pts, s));
-  PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s));
+  PXO_TRY(launch_mlp_fwd(cfg, pk0, t.c.pts, t.c.M, t.c.raw_rgb, t.c.raw_sigma, t.c.acts, t.c.enc, t.c.mask, s, tile_counter));
   if (dr.noisy) PXO_TRY(launch_add_noise(t.c.raw_sigma, B * Nc, cfg->noise_std, nullptr, dr.seed, 3, s));   // models.py:258-264
   if (pixels)
     return launch_shade_composite_train(cfg, t.c.raw_rgb, t.c.raw_sigma, t.c.z, d, v, pixels, B, Nc, nullptr,
@@ -223,16 +232,23 @@ static int forward_coarse(const PxoCfg* cfg, TrainWs& t, const float* pk0, const
 
 static int forward_fine(const PxoCfg* cfg, TrainWs& t, const float* pk1, const float* o, const float* d, const float* v,
                         int64_t B, const Draws& dr, const float* pixels, float* rgb_f, float* disp_f, float* acc_f,
-                        hipStream_t s) {
+                        hipStream_t s, unsigned int* tile_counter = nullptr) {
   const int Nc = cfg->num_coarse_samples, Nf = cfg->num_fine_samples;
   PXO_TRY(launch_sample_pdf(t.c.z, t.c.weights, o, d, B, Nc, Nf, dr.u, t.f.z, t.f.pts, s));
-  PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s));
+  PXO_TRY(launch_mlp_fwd(cfg, pk1, t.f.pts, t.f.M, t.f.raw_rgb, t.f.raw_sigma, t.f.acts, t.f.enc, t.f.mask, s, tile_counter));
   if (dr.noisy) PXO_TRY(launch_add_noise(t.f.raw_sigma, B * (Nc + Nf), cfg->noise_std, nullptr, dr.seed, 4, s));   // :318-324
   if (pixels)
     return launch_shade_composite_train(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, pixels, B, Nc + Nf, nullptr,
                                         nullptr, t.f.ray_sse, t.f.d_raw_rgb, t.f.d_raw_sigma, t.n_sp, t.sp_exp, s);
   return launch_shade_composite_fwd(cfg, t.f.raw_rgb, t.f.raw_sigma, t.f.z, d, v, B, Nc + Nf, rgb_f, disp_f, acc_f,
                                     t.f.weights, s);
+}
+
+// diagnostic: `blocks` workgroups of `threads` threads that do nothing for `micros` microseconds of the device's
+// constant-rate clock (what a ring all-reduce's kernel looks like to the kernels it shares the GPU with)
+__global__ void occupy_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 }  // namespace pxo
@@ -242,7 +258,39 @@ using namespace pxo;
 extern "C" {
 
 const char* pxo_last_error(void) { return g_last_error.c_str(); }
-int pxo_version(void) { return 1; }
+int pxo_version(void) { return PXO_ABI_VERSION; }
+size_t pxo_cfg_bytes(void) { return sizeof(PxoCfg); }
+
+int pxo_set_tuning(int knob, int value) {
+  switch (knob) {
+    case PXO_TUNE_TILE_SCHED:
+      PXO_REQUIRE(value == 0 || value == 1, "pxo_set_tuning: tile schedule must be 0 (static stride) or 1 (device counter), got %d", value);
+      g_tune_tile_sched = value;
+      return PXO_OK;
+    case PXO_TUNE_WGRAD_RANGES:
+      PXO_REQUIRE(value >= 0 && value <= num_cus(), "pxo_set_tuning: row ranges per layer must be 0 (built-in choice) .. %d, got %d",
+                  num_cus(), value);
+      g_tune_wgrad_ranges = value;
+      return PXO_OK;
+    case PXO_TUNE_WGRAD_SKINNY_RANGES:
+      PXO_REQUIRE(value >= 0 && value <= 2 * num_cus(), "pxo_set_tuning: row ranges of the skinny products must be 0 (built-in choice) .. %d, got %d",
+                  2 * num_cus(), value);
+      g_tune_wgrad_skinny_ranges = value;
+      return PXO_OK;
+    default:
+      set_error("pxo_set_tuning: unknown knob %d", knob);
+      return PXO_ERR_ARG;
+  }
+}
+int pxo_get_tuning(int knob, int* value) {
+  PXO_REQUIRE(value != nullptr, "pxo_get_tuning: NULL pointer");
+  switch (knob) {
+    case PXO_TUNE_TILE_SCHED: *value = g_tune_tile_sched; return PXO_OK;
+    case PXO_TUNE_WGRAD_RANGES: *value = g_tune_wgrad_ranges; return PXO_OK;
+    case PXO_TUNE_WGRAD_SKINNY_RANGES: *value = g_tune_wgrad_skinny_ranges; return PXO_OK;
+    default: set_error("pxo_get_tuning: unknown knob %d", knob); return PXO_ERR_ARG;
+  }
+}
 int pxo_tile_rows(void) { return kTM; }
 
 int pxo_param_layout(const PxoCfg* cfg, PxoLeaf* leaves, int64_t* floats_per_mlp) {
@@ -488,8 +536,7 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
     set_error("pxo_train_fwd_bwd: training runs in float32 only (mlp_precision must be PXO_MLP_F32)");
     return PXO_ERR_UNSUPPORTED;
   }
-  const int Nf = cfg->num_fine_samples;
-  if (Nf > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
+  if (cfg->num_fine_samples > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
   hipStream_t s = (hipStream_t)stream;
   TrainWs t;
   carve_train(cfg, B, ws, true, t);
@@ -503,18 +550,30 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   // weight_l2 = sum(p^2) / n (train.py:101-108) depends on the parameters only: its partial sums ride in the step's first
   // launch, together with every uniform draw
   float* const sumsq_partial = t.scalars;
+  // Tile counters of the step's four persistent MLP launches (forward / backward(data) of each level), zeroed by the step's
+  // first launch: the dense kernels take their tiles from them when PXO_TUNE_TILE_SCHED = 1, the skipping backward always
+  unsigned int* const counters = reinterpret_cast<unsigned int*>(t.scalars + 100);
+  const bool dyn = tune_tile_sched() != 0;
+  unsigned int* const cnt_fwd_c = dyn ? counters + 0 : nullptr;
+  unsigned int* const cnt_fwd_f = dyn ? counters + 2 : nullptr;
+  unsigned int* const cnt_bwd_c = (dyn || cfg->skip_zero_rows) ? counters + 1 : nullptr;
+  unsigned int* const cnt_bwd_f = (dyn || cfg->skip_zero_rows) ? counters + 3 : nullptr;
+  const int Nf = cfg->num_fine_samples;
   Draws dr;
-  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, sp_points, seed, s, dr, params, 2 * n_mlp, sumsq_partial));
+  PXO_TRY(prepare_draws(cfg, t, B, randomized, t_rand, u, sp_points, seed, s, dr, params, 2 * n_mlp, sumsq_partial, counters, 4));
   // coarse level: forward, losses (train.py:77-98), reverse of the compositing, reverse through MLP_0.  Nothing of the fine
   // level feeds MLP_0's gradient (the fine sample positions carry no gradient, model_utils.py:286), so it is complete here
   // -- a quarter into the step -- and its all-reduce can ride under the fine level.
-  PXO_TRY(forward_coarse(cfg, t, packed_fwd0, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
+  PXO_TRY(forward_coarse(cfg, t, packed_fwd0, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s,
+                         cnt_fwd_c));
   // skip_zero_rows: rows with an exactly zero upstream gradient are left out of the reverse pass (bit-identical gradients)
-  uint8_t* const live_c = cfg->skip_zero_rows ? t.c.live : nullptr;
-  uint8_t* const live_f = cfg->skip_zero_rows ? t.f.live : nullptr;
-  unsigned int* const tile_counter = cfg->skip_zero_rows ? reinterpret_cast<unsigned int*>(t.scalars + 100) : nullptr;
+  // (a pass whose weight-gradient row ranges would not fit the kernels' live-chunk lists -- > 32,768 rows per range, i.e.
+  // more than 8.4 M sample rows on 256 CUs -- makes the whole reverse pass dense: same bits, no saving)
+  const bool skip = cfg->skip_zero_rows != 0 && wgrad_skip_supported(t.c.M) && (Nf == 0 || wgrad_skip_supported(t.f.M));
+  uint8_t* const live_c = skip ? t.c.live : nullptr;
+  uint8_t* const live_f = skip ? t.f.live : nullptr;
   PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c,
-                              tile_counter, s));
+                              cnt_bwd_c, s, true));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
                                  grads, t.wgrad_ws, t.wgrad_bytes, live_c, s));
   if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads, params, n_mlp, wd_coef, s));
@@ -523,9 +582,10 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
     return PXO_ERR_HIP;
   }
   if (Nf > 0) {
-    PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s));
+    PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s,
+                         cnt_fwd_f));
     PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, live_f,
-                                tile_counter, s));
+                                cnt_bwd_f, s, true));
     PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
                                    grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, live_f, s));
   } else {
@@ -557,7 +617,11 @@ int pxo_train_backward_work(const PxoCfg* cfg, int64_t B, void* ws, size_t ws_by
   hipStream_t s = (hipStream_t)stream;
   const int64_t nc = (t.c.M + kLiveRows - 1) / kLiveRows, nf = cfg->num_fine_samples > 0 ? (t.f.M + kLiveRows - 1) / kLiveRows : 0;
   *total_chunks = nc + nf;
-  if (!cfg->skip_zero_rows) { *live_chunks = nc + nf; return PXO_OK; }
+  // dense pass (also when the step fell back to it because a row range would not fit the live lists): every chunk is live
+  if (!cfg->skip_zero_rows || !wgrad_skip_supported(t.c.M) || (nf > 0 && !wgrad_skip_supported(t.f.M))) {
+    *live_chunks = nc + nf;
+    return PXO_OK;
+  }
   unsigned long long* cnt = reinterpret_cast<unsigned long long*>(t.scalars + 96);     // 8-byte aligned tail of the scalars block
   if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return PXO_ERR_HIP; }
   PXO_TRY(launch_count_live(t.c.live, nc, cnt, s));
@@ -601,6 +665,18 @@ int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, con
   }
   return launch_adam_pack(cfg, params, m, v, grads, lr, step, grad_scale, packed_fwd0, packed_bwd0, packed_fwd1,
                           packed_bwd1, (hipStream_t)stream);
+}
+
+int pxo_occupy_cus(int blocks, int threads, float micros, void* stream) {
+  PXO_REQUIRE(blocks >= 1 && blocks <= 4096 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && micros >= 0.f &&
+                  micros <= 1e6f,
+              "pxo_occupy_cus: bad arguments (blocks %d, threads %d, micros %g)", blocks, threads, (double)micros);
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    khz = 100000;                                                    // gfx9: 100 MHz constant clock
+  const long long ticks = (long long)((double)micros * 1e-3 * (double)khz);
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, ticks);
+  return check_launch("occupy_cus");
 }
 
 int pxo_profile_enable(int tag_mask) {

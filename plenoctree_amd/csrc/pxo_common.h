@@ -136,7 +136,7 @@ int validate_cfg(const PxoCfg* cfg);
 int num_cus();
 int mlp_bwd_partials(int64_t M);   // number of [9][256] tile partials (slots) mlp_bwd_data writes for M rows
 
-// HIP-event bracket around one kernel launch (active only after pxo_profile_enable(1))
+// HIP-event bracket around one kernel launch (active for the tags in pxo_profile_enable's mask)
 struct KernelTimer {
   KernelTimer(int tag, int64_t rows, hipStream_t s);
   ~KernelTimer();
@@ -148,17 +148,29 @@ int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, in
 
 // ---- launchers implemented in the kernel translation units -----------------------------
 int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s);
+// tile_counter (may be NULL = static tile stride): a ZERO device word; the persistent workgroups of the training
+// instantiation then take their tiles from it (mlp_kernels.hip TileTicket)
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
                    float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
-                   hipStream_t s);
+                   hipStream_t s, unsigned int* tile_counter = nullptr);
 // chunk_live (may be NULL = dense): one byte per kLiveRows rows, WRITTEN by the backward(data) kernel (1: some row of the
 // chunk has a non-zero upstream gradient) and READ by the weight-gradient kernels, which skip dead chunks
 __host__ __device__ inline int64_t live_flags(int64_t M) { return (M + kLiveRows - 1) / kLiveRows + kTM / kLiveRows; }
-// tile_counter (skipping mode only, may be NULL): a zeroed device word; the persistent workgroups then TAKE tiles from it
-// instead of striding over them, so that skipped tiles do not leave workgroups idle
+// tile_counter (may be NULL = static tile stride): a device word; the persistent workgroups then TAKE tiles from it
+// instead of striding over them (skipped tiles do not leave workgroups idle; a late-starting workgroup is not the tail).
+// counter_is_zero: the caller zeroed it on the stream already (the train step's first launch does); otherwise a memset is
+// enqueued here.
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
-                        float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s);
+                        float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s,
+                        bool counter_is_zero = false);
+// run-time choices between implementations of the same result (pxo_set_tuning; A/B sessions and equality tests)
+int tune_tile_sched();        // PXO_TUNE_TILE_SCHED: 0 static stride, 1 device counter (dense training kernels)
+int tune_wgrad_ranges();      // PXO_TUNE_WGRAD_RANGES: 0 = built-in choice, n > 0 = row ranges per layer of the 256x256 products
+int tune_wgrad_skinny_ranges();  // PXO_TUNE_WGRAD_SKINNY_RANGES: the same for the enc-based pair and the head product
+// can the weight-gradient kernels skip dead chunks for a pass of M rows (every row range fits a workgroup's live list)?
+// If not the whole reverse pass of the step runs dense (pxo_train_fwd_bwd decides up front).
+bool wgrad_skip_supported(int64_t M);
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,
@@ -207,8 +219,9 @@ struct UniformJob { uint64_t stream_id; int64_t n; float lo, hi; float* out; };
 // sq_x != NULL: the same launch also writes the kSumsqBlocks fixed-order partial sums of squares of sq_x[0 .. sq_n) (the
 // parameter norm of weight_l2, train.py:101-108: it depends on the parameters only, so it rides with the step's first launch)
 constexpr int kSumsqBlocks = 64;
+// zero_words != NULL: the same launch also zeroes n_zero (<= 256) device words (the tile counters of the step's MLP launches)
 int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s, const float* sq_x = nullptr,
-                        int64_t sq_n = 0, float* sq_partial = nullptr);
+                        int64_t sq_n = 0, float* sq_partial = nullptr, unsigned int* zero_words = nullptr, int n_zero = 0);
 int launch_finalize_stats(const float* sse_f, const float* sse_c, const float* sp_exp, const float* sumsq_partial,
                           int64_t B, int64_t n_sp, float sp_weight, int64_t n_params, float* stats, hipStream_t s);
 int launch_adam_pack(const PxoCfg* cfg, float* p, float* m, float* v, const float* g, float lr, int64_t step,

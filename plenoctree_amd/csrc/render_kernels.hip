@@ -588,12 +588,15 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
 }
 
-struct UniformJobs { UniformJob job[3]; int n_jobs; const float* sq_x; int64_t sq_n; float* sq_partial; };
+struct UniformJobs { UniformJob job[3]; int n_jobs; const float* sq_x; int64_t sq_n; float* sq_partial; unsigned int* zero_words; int n_zero; };
 
 // blockIdx.y selects the job; element idx of a job is word idx % 4 of the Philox block with counter idx / 4 and the
 // job's stream id in the upper counter words
 __global__ __launch_bounds__(256) void uniform_kernel(uint64_t seed, UniformJobs J) {
+  // the tile counters of the step's persistent MLP launches (mlp_kernels.hip TileTicket) start from zero
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < J.n_zero) J.zero_words[threadIdx.x] = 0u;
   if ((int)blockIdx.y == J.n_jobs) {
+    if (J.sq_x == nullptr) return;
     // parameter-norm partials (weight_l2 = sum(p^2) / n, train.py:101-108): kSumsqBlocks blocks, strided loads, fixed-order
     // tree in LDS; finalize_stats_kernel adds the partials in order
     if (blockIdx.x >= kSumsqBlocks) return;
@@ -692,7 +695,7 @@ int launch_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int
 }
 
 int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipStream_t s, const float* sq_x, int64_t sq_n,
-                        float* sq_partial) {
+                        float* sq_partial, unsigned int* zero_words, int n_zero) {
   UniformJobs J;
   int64_t qmax = 0;
   int nj = 0;
@@ -703,12 +706,17 @@ int launch_uniform_jobs(uint64_t seed, const UniformJob* jobs, int n_jobs, hipSt
     if (q > qmax) qmax = q;
   }
   const bool sq = sq_x != nullptr && sq_partial != nullptr;
-  if (nj == 0 && !sq) return PXO_OK;
+  if (zero_words == nullptr || n_zero < 0) n_zero = 0;
+  if (n_zero > 256) { set_error("uniform: at most 256 words can be zeroed by the launch (got %d)", n_zero); return PXO_ERR_ARG; }
+  if (nj == 0 && !sq && n_zero == 0) return PXO_OK;
   for (int i = nj; i < 3; ++i) J.job[i] = UniformJob{0, 0, 0.f, 0.f, nullptr};
-  J.n_jobs = nj; J.sq_x = sq_x; J.sq_n = sq_n; J.sq_partial = sq_partial;
+  J.n_jobs = nj; J.sq_x = sq ? sq_x : nullptr; J.sq_n = sq_n; J.sq_partial = sq_partial;
+  J.zero_words = zero_words; J.n_zero = n_zero;
   int64_t bx = (qmax + 255) / 256;
   if (sq && bx < kSumsqBlocks) bx = kSumsqBlocks;
-  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)bx, nj + (sq ? 1 : 0)), dim3(256), 0, s, seed, J);
+  if (bx < 1) bx = 1;
+  const int by = nj + (sq ? 1 : 0);
+  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)bx, by > 0 ? by : 1), dim3(256), 0, s, seed, J);
   return check_launch("uniform");
 }
 

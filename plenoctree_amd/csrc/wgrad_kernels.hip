@@ -14,6 +14,7 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
+constexpr int kMaxLiveChunks = 2048;   // live-chunk list of a SPARSE workgroup (LDS): row ranges of at most 32,768 rows
 
 
 // Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over
@@ -209,7 +210,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(
   // loop then walks the list instead of 0..nchunks-1 (same accumulation order over the chunks that contribute: bit-identical
   // sums).  A separate instantiation: in the dense kernel the chunk index stays the loop counter (a scalar; as a value read
   // from LDS it cost the dense 256x256 product 5 %, measured).
-  constexpr int kMaxLive = SPARSE ? 2048 : 1;          // longer ranges (> 32 k rows) run dense
+  // (ranges longer than kMaxLiveChunks chunks never reach a SPARSE launch: wgrad_skip_supported / the launcher's check --
+  // in skipping mode backward(data) leaves the dz rows of dead tiles unwritten, so a dense walk here would read garbage)
+  constexpr int kMaxLive = SPARSE ? kMaxLiveChunks : 1;
   __shared__ uint16_t live_list[kMaxLive];
   __shared__ int live_count;
   const bool sparse = SPARSE && chunk_live != nullptr && nchunks <= kMaxLive;
@@ -367,12 +370,44 @@ int launch_count_live(const uint8_t* chunk_live, int64_t n, unsigned long long* 
   return check_launch("count_live");
 }
 
+
 static void split_rows(int64_t M, int64_t target, int64_t* rows_per_wg, int* P) {
   int64_t rpw = (M + target - 1) / target;
   rpw = (rpw + kKC - 1) / kKC * kKC;
   if (rpw < kKC) rpw = kKC;
   *rows_per_wg = rpw;
   *P = (int)((M + rpw - 1) / rpw);
+}
+
+// The split of a pass of M rows: row ranges per layer of the 256x256 products / of the skinny products.
+//  * big passes (>= 1024 rows per CU): one range per CU and layer (NL whole waves of workgroups on the 2 num_cus() slots);
+//  * smaller ones: 4 num_cus() / NL ranges (4 waves) -- round 3, rays/s at 4096 / 1024 / 512 rays per step on 256 CUs:
+//    256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k / 144.3 k / 127.9 k (one launch per layer: 159.7 k /
+//    139.9 k / 120.3 k): long ranges lose on big passes (the two column halves drift apart and the shared operand stops
+//    hitting L2), short ones pay 64 MB of slab traffic per layer;
+//  * the skinny products run two workgroups per CU: 2 num_cus() ranges, num_cus() below 512 rows per CU (round 3, ms per step
+//    at 512 / 1024 / 4096 rays: 512 ranges 3.732 / 6.686 / 24.19, 256 ranges 3.716 / 6.689 / 24.28, 384: 3.739 / 6.722 /
+//    24.41, 128: slower).
+// pxo_set_tuning(PXO_TUNE_WGRAD_RANGES / PXO_TUNE_WGRAD_SKINNY_RANGES) overrides either (A/B sessions).
+struct WgradSplit { int64_t rpw_main; int P_main; int64_t rpw_skinny; int P_skinny; };
+static WgradSplit wgrad_split(int64_t M) {
+  constexpr int NL = kDepth - 1;
+  WgradSplit w;
+  int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
+  if (tune_wgrad_ranges() > 0) ranges = tune_wgrad_ranges();
+  if (ranges > num_cus()) ranges = num_cus();
+  split_rows(M, ranges, &w.rpw_main, &w.P_main);
+  int skinny = M < (int64_t)512 * num_cus() ? num_cus() : 2 * num_cus();
+  if (tune_wgrad_skinny_ranges() > 0) skinny = tune_wgrad_skinny_ranges();
+  if (skinny > 2 * num_cus()) skinny = 2 * num_cus();
+  split_rows(M, skinny, &w.rpw_skinny, &w.P_skinny);
+  return w;
+}
+// zero-row skipping needs every row range to fit the workgroup's live-chunk list
+bool wgrad_skip_supported(int64_t M) {
+  if (M <= 0) return true;
+  const WgradSplit w = wgrad_split(M);
+  return w.rpw_main <= (int64_t)kMaxLiveChunks * kLiveRows && w.rpw_skinny <= (int64_t)kMaxLiveChunks * kLiveRows;
 }
 
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
@@ -416,10 +451,14 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // the skinny products (enc-based pair, heads): two workgroups per CU.  Issuing them on side streams beside the 256x256 launch was measured too (round 3,
   // 512 rays per step): 4.05 vs 3.96 ms per step -- the HBM-leaning workgroups take CU slots from the MFMA-bound ones
   // early and the step gets longer, so the three launches stay in stream order.
-  int64_t rpw2; int P2;
-  // (round 3, ms per step at 512 / 1024 / 4096 rays: 512 ranges 3.732 / 6.686 / 24.19, 256 ranges 3.716 / 6.689 / 24.28,
-  // 384: 3.739 / 6.722 / 24.41, 128: slower -- small passes take the 256, whose slabs cost the reduction half as much)
-  split_rows(M, M < (int64_t)512 * num_cus() ? (int64_t)num_cus() : 2 * (int64_t)num_cus(), &rpw2, &P2);
+  const WgradSplit split = wgrad_split(M);
+  if (chunk_live && !wgrad_skip_supported(M)) {
+    set_error("mlp_bwd_weights: zero-row skipping with row ranges of %lld / %lld rows (> %d chunks of %d rows per workgroup); "
+              "the caller must run this pass dense (wgrad_skip_supported)", (long long)split.rpw_main,
+              (long long)split.rpw_skinny, kMaxLiveChunks, kLiveRows);
+    return PXO_ERR_UNSUPPORTED;
+  }
+  const int64_t rpw2 = split.rpw_skinny; const int P2 = split.P_skinny;
   const float* h7 = acts + (int64_t)7 * MW;
   auto head = [&](float* slab) {
     KernelTimer timer(PXO_PROF_WGRAD_OTHER, M, s);
@@ -445,14 +484,8 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   // stacks, so layer l is "group l-1" of the kernel with layer_stride = M*256; then ONE launch reduces every slab set of
   // the pass (and the bias partials).  14 + 12 launches per step fewer than a launch per product, and the layers'
   // ramp-ups and tails overlap.
-  // Row ranges per layer: the grid is NL x ranges x 2 column halves on 2 num_cus() slots, all of equal work, so whole
-  // "waves" of workgroups are what to aim for: num_cus() ranges = NL waves; 4 num_cus() / NL = 4 waves.  Measured
-  // (rays/s at 4096 / 1024 / 512 rays per step, 256 CUs): 256 ranges 161.0 k / 141.6 k / 123.6 k, 146 ranges 156.5 k /
-  // 144.3 k / 127.9 k (one launch per layer: 159.7 k / 139.9 k / 120.3 k) - long ranges lose on big passes (the two
-  // column halves drift apart and the shared operand stops hitting L2), short ones pay 64 MB of slab traffic per layer.
-  int ranges = M >= (int64_t)1024 * num_cus() ? num_cus() : (4 * num_cus() / NL > 0 ? 4 * num_cus() / NL : 1);
-  int64_t rpwb; int Pb;
-  split_rows(M, ranges, &rpwb, &Pb);
+  // Row ranges per layer: wgrad_split above (the grid is NL x ranges x 2 column halves on 2 num_cus() slots, all of equal work).
+  const int64_t rpwb = split.rpw_main; const int Pb = split.P_main;
   float* const slab_main = reinterpret_cast<float*>(ws);
   float* const slab_enc = slab_main + (size_t)NL * num_cus() * kW * kW;
   float* const slab_head = slab_enc + (size_t)2 * num_cus() * kEncPad * 2 * kW;

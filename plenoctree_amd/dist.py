@@ -132,6 +132,10 @@ class GradReducer:
                     w0.wait()
                 self.bucket0_done = torch.cuda.Event(enable_timing=True)
                 self.bucket0_done.record(self.side)
+        if w0 is None:
+            # an injected `all_reduce` (tests, scripts/contention_probe.py) returns no Work handle: whatever it enqueued on
+            # the side stream is joined explicitly, or Adam could read bucket 0 before its reduction has finished
+            torch.cuda.current_stream().wait_stream(self.side)
         w1 = self._reduce(bucket1, True)            # ordered after everything queued on the current stream
         # the caller's stream waits for both collectives directly (Work.wait orders the CURRENT stream behind the work):
         # no event hop through the side stream on the way back

@@ -354,6 +354,27 @@ def grid_sigma(cfg, packed_fwd, reso, x0, x1, offset, scale, out=None):
 PROF_MLP_FWD, PROF_MLP_BWD_DATA, PROF_WGRAD_MAIN, PROF_WGRAD_OTHER, PROF_NUM_TAGS = 0, 1, 2, 3, 4
 
 
+TUNE_TILE_SCHED, TUNE_WGRAD_RANGES, TUNE_WGRAD_SKINNY_RANGES = 0, 1, 2        # PXO_TUNE_* of include/plenoctree_hip.h
+
+
+def set_tuning(knob, value):
+    """pxo_set_tuning: choose between implementations of the same result (A/B sessions, equality tests)."""
+    check(_lib.load().pxo_set_tuning(int(knob), int(value)), "pxo_set_tuning")
+
+
+def get_tuning(knob):
+    v = ctypes.c_int(0)
+    check(_lib.load().pxo_get_tuning(int(knob), ctypes.byref(v)), "pxo_get_tuning")
+    return v.value
+
+
+def occupy_cus(blocks, threads, micros, stream=None):
+    """pxo_occupy_cus: `blocks` idle workgroups for `micros` us on `stream` (a torch.cuda.Stream; default: the current one)."""
+    _require_gpu()
+    h = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(_lib.load().pxo_occupy_cus(int(blocks), int(threads), float(micros), h), "pxo_occupy_cus")
+
+
 def profile_enable(on=True, tags=None):
     """HIP-event brackets around the tagged kernel launches: all tags (on=True), none (False), or the listed `tags`.
     Every bracket costs the stream two event records (~5 us each between kernels that would otherwise run back to back)."""

@@ -224,6 +224,9 @@ def philox_randint(seed, stream_id, count, n):
 
 # ---- the mid-scale trained-PSNR twin (tests/golden/make_trained_twin.py <-> test_trained_psnr_twin_512_rays) ------------
 TWIN_RAYS, TWIN_STEPS = 512, 300
+# the long twin (round 5): leaves the 14 dB regime -- HIP leg 23.9 dB on held-out views (scripts/twin_search.py,
+# profiles/r05a_twin_search.jsonl: 1024 x 1500 -> 23.93, 1024 x 2000 -> 24.83, 2048 x 1000 -> 22.42 dB)
+TWIN_LONG_RAYS, TWIN_LONG_STEPS = 1024, 1500
 
 
 def _twin_args():

@@ -29,22 +29,31 @@ def main():
     from _cpu_feeder import feeder_for
     from plenoctree_amd.nerf_sh.nerf import datasets
     datasets.Dataset.feeder_factory = staticmethod(feeder_for)
-    B, steps = H.TWIN_RAYS, H.TWIN_STEPS
+    # `python make_trained_twin.py`            the 512 x 300 twin (round 4)
+    # `python make_trained_twin.py long`       the 1024 x 1500 twin (round 5: leaves the 14 dB regime, ~24 dB; ~2.5 h on 8 cores)
+    B, steps = (H.TWIN_LONG_RAYS, H.TWIN_LONG_STEPS) if sys.argv[1:] == ["long"] else (H.TWIN_RAYS, H.TWIN_STEPS)
     cfg = O.Cfg()
     torch.set_num_threads(os.cpu_count() or 1)
     flat0 = O.flatten_params(O.init_params(cfg, seed=20200823))
     p, m, v = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
+    rays, px = H.twin_heldout()
     t0 = time.time()
+    trace = {}
     for step, batch, t_rand, u, sp, lr in H.twin_steps(B, steps, cfg):
         p, m, v, st, _ = O.train_step(p, m, v, step, O.Rays(*batch["rays"]), batch["pixels"], cfg, t_rand, u, sp, lr)
         if step % 10 == 0:
             print(f"step {step}: loss {float(st['loss']):.5f} psnr {float(st['psnr']):.3f}  ({time.time() - t0:.0f} s)", flush=True)
-    rays, px = H.twin_heldout()
+        if (step + 1) % 250 == 0 and step + 1 < steps:
+            with torch.no_grad():
+                trace[step + 1] = H._psnr(O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0], px)
+            print(f"held-out PSNR after {step + 1} steps: {trace[step + 1]:.4f} dB", flush=True)
+            np.savez_compressed(f"/tmp/trained_twin_{B}x{steps}_at{step + 1}.npz", params=p.numpy(), m=m.numpy(), v=v.numpy())
     with torch.no_grad():
         trained = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
         init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]
     out = dict(params=p.numpy(), rays_per_step=B, steps=steps, psnr_init=H._psnr(init, px), psnr_trained=H._psnr(trained, px),
-               torch_version=torch.__version__, threads=torch.get_num_threads())
+               torch_version=torch.__version__, threads=torch.get_num_threads(), oracle_s=time.time() - t0,
+               trace_steps=np.array(sorted(trace), np.int64), trace_psnr=np.array([trace[k] for k in sorted(trace)], np.float64))
     print({k: v for k, v in out.items() if k != "params"})
     np.savez_compressed(os.path.join(HERE, f"trained_twin_{B}x{steps}.npz"), **out)
 

@@ -1159,6 +1159,82 @@ def test_skip_zero_rows_is_bit_identical(deg, shift, wd):
         assert l1 <= t1
 
 
+def _one_train_step(ops, dev, cfg, flat, B, skip, seed=3):
+    n = flat.numel() // 2
+    rays = make_rays(B)
+    px = torch.rand(B, 3, generator=torch.Generator().manual_seed(2))
+    g = torch.Generator().manual_seed(seed)
+    t_rand, u = torch.rand(B, 64, generator=g), torch.rand(B, 128, generator=g)
+    sp = (torch.rand(cfg.sparsity_npoints, 3, generator=g) * 2 - 1) * 1.5
+    pcfg = pxo_cfg(ops, cfg)
+    pcfg.skip_zero_rows = skip
+    fd = flat.to(dev)
+    packed = [ops.pack_weights(pcfg, fd[i * n:(i + 1) * n].contiguous()) for i in range(2)]
+    grads = torch.full_like(fd, float("nan")); stats = torch.zeros(6, device=dev)
+    ws = torch.empty(ops.train_workspace_bytes(pcfg, B), dtype=torch.uint8, device=dev)
+    ws.fill_(0xFF)
+    ops.train_fwd_bwd(pcfg, fd, packed, *[r.to(dev) for r in rays], px.to(dev), grads, stats, ws, randomized=True,
+                      t_rand=t_rand.to(dev), u=u.to(dev), sp_points=sp.to(dev))
+    live, total = ops.train_backward_work(pcfg, B, ws)
+    return grads.cpu(), stats.cpu(), live, total
+
+
+@pytest.mark.parametrize("B", [600, 2500])
+def test_tile_counter_schedule_is_bit_identical(B):
+    """PXO_TUNE_TILE_SCHED: the persistent workgroups of the dense training kernels take their tiles from a device counter
+    instead of a static stride.  A slot's rows, relu-mask words and bias partial are a function of the slot alone, so gradients
+    and Stats must not change by a bit -- B = 600: two rounds of tiles in the coarse pass, ragged half tiles in the fine one;
+    B = 2500: 4 / 11 whole rounds + a half-tile round on 256 CUs -- and the skipping pass (always on the counter) must agree too."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sparsity_npoints=777)
+    flat = make_params(cfg)
+    try:
+        ops.set_tuning(ops.TUNE_TILE_SCHED, 0)
+        g0, s0, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
+        ops.set_tuning(ops.TUNE_TILE_SCHED, 1)
+        assert ops.get_tuning(ops.TUNE_TILE_SCHED) == 1
+        g1, s1, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
+        g2, s2, _, _ = _one_train_step(ops, dev, cfg, flat, B, 1)
+        g3, s3, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)       # again: the counters are re-zeroed by every step
+    finally:
+        ops.set_tuning(ops.TUNE_TILE_SCHED, 0)
+    assert bool(torch.isfinite(g0).all())
+    for g, s_ in ((g1, s1), (g2, s2), (g3, s3)):
+        assert torch.equal(g0, g) and torch.equal(s0, s_)
+
+
+def test_wgrad_ranges_tuning_and_long_ranges_in_skipping_mode():
+    """PXO_TUNE_WGRAD_RANGES / _SKINNY_RANGES change the split-K row ranges of the weight-gradient products: a different
+    (still fixed) summation order, so results agree to float32 round-off, not bit for bit.  With row ranges longer than the
+    skipping kernels' live-chunk list (32,768 rows: here forced with 2 ranges over 115,977 rows) the whole reverse pass must
+    run DENSE -- the workspace is poisoned with NaNs, so a dense walk over the dz rows a skipping backward(data) left unwritten
+    (what a silent per-kernel fallback would do) shows up as NaN gradients -- and must report every chunk as live."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sparsity_npoints=777)
+    flat = make_params(cfg)
+    B = 600
+    try:
+        g0, s0, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
+        ops.set_tuning(ops.TUNE_WGRAD_RANGES, 73); ops.set_tuning(ops.TUNE_WGRAD_SKINNY_RANGES, 100)
+        g1, s1, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
+        g1s, s1s, l1, t1 = _one_train_step(ops, dev, cfg, flat, B, 1)
+        ops.set_tuning(ops.TUNE_WGRAD_RANGES, 2); ops.set_tuning(ops.TUNE_WGRAD_SKINNY_RANGES, 0)
+        g2, s2, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
+        g2s, s2s, l2, t2 = _one_train_step(ops, dev, cfg, flat, B, 1)
+    finally:
+        ops.set_tuning(ops.TUNE_WGRAD_RANGES, 0); ops.set_tuning(ops.TUNE_WGRAD_SKINNY_RANGES, 0)
+    assert torch.equal(s0, s1) and torch.equal(s0, s2)                     # the forward does not depend on the split
+    for g in (g1, g2):
+        assert bool(torch.isfinite(g).all())
+        rel = float((g.double() - g0.double()).norm() / g0.double().norm())
+        assert rel < 2e-6, rel
+    assert torch.equal(g1, g1s) and l1 < t1                                 # skipping with ranges that fit: same bits, chunks skipped
+    assert torch.equal(g2, g2s) and torch.equal(s2, s2s) and l2 == t2       # ranges too long for the live lists: dense, loudly so
+    for knob, bad in ((ops.TUNE_TILE_SCHED, 2), (ops.TUNE_WGRAD_RANGES, -1), (ops.TUNE_WGRAD_RANGES, 100000), (99, 0)):
+        with pytest.raises(Exception, match="pxo_set_tuning"):
+            ops.set_tuning(knob, bad)
+
+
 def test_sample_batch_equals_the_three_separate_launches():
     """pxo_sample_batch (Dataset._next_train for one image in one launch) against pxo_randint + pxo_generate_rays + the gather
     of the image's colours: bit for bit, odd batch size included; and through datasets.Synthetic, whose batches must not

@@ -58,6 +58,9 @@ def parse(argv=None):
                         "multi-GPU code path on a 1-GPU box)")
     p.add_argument("--no-kernel-events", action="store_true",
                    help="A/B only: no HIP events around the dominant kernels in the timed region (no roofline leg)")
+    p.add_argument("--per-host-image", action="store_true",
+                   help="batches as the reference draws them on ONE host: one image per step, its pixels sharded over the ranks "
+                        "(datasets shard=(rank, world)); default: every rank its own image (the reference's multi-host sampler)")
     p.add_argument("--tune", default="", help="A/B only: pxo_set_tuning knobs, e.g. tile_sched=1,wgrad_ranges=73,wgrad_skinny_ranges=128 "
                                               "(same results, different schedule; recorded in the line as `tuning`)")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
@@ -277,7 +280,10 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, even
     args = flags_for(a, preset, per_gpu, **flag_over)
     model, params = models.construct_nerf(args, job.device)
     state = models.TrainState(model.cfg, params)
-    dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
+    if a.per_host_image:
+        dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473, shard=(job.rank, job.world))
+    else:
+        dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
     reducer = job.reducer(exchange)
     snap = {}
 

@@ -212,10 +212,12 @@ int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t
 /* Dataset._next_train for one image (nerf_sh/nerf/datasets.py:159-166: `ray_indices = np.random.randint(0, H*W, (B,))`, the
  * rays and the pixels of those indices) in one launch: pixel id i = pxo_randint's element i of stream (seed, stream_id)
  * mod W*H, its ray as pxo_generate_rays, its colour from image_rgb [H*W,3] (the resident training image) -- bit for bit what
- * the three separate calls give.  pixel_ids [B] may be NULL. */
+ * the three separate calls give.  pixel_ids [B] may be NULL.  `first`: the B elements are elements first .. first + B - 1
+ * of the stream -- a rank's shard of ONE global draw (the reference's single-host step: one image, its batch_size pixels
+ * sharded over the local devices, nerf_sh/nerf/datasets.py:159-166 + nerf_sh/nerf/utils.py:518-522); 0 = the whole draw. */
 int pxo_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal,
-                     const float* image_rgb, int64_t B, int64_t* pixel_ids, float* origins, float* directions,
-                     float* viewdirs, float* pixels, void* stream);
+                     const float* image_rgb, int64_t B, int64_t first, int64_t* pixel_ids, float* origins,
+                     float* directions, float* viewdirs, float* pixels, void* stream);
 
 /* The same for the `image_batching` sampler (nerf_sh/nerf/datasets.py:137-141,152-157: rays of ALL
  * images flattened into one table): c2w [n_cams,3,4], ray id r -> camera r / (W*H), pixel r % (W*H). */
@@ -313,9 +315,9 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
  * sessions (bench.py --tune) and equality tests; nothing is read from the environment.
  *   PXO_TUNE_TILE_SCHED    how the persistent workgroups of the dense training kernels (mlp_fwd with saved tensors,
  *                          mlp_bwd_data) pick their 128-row tiles inside pxo_train_fwd_bwd*: 0 = static stride,
- *                          1 = from a device counter, so that a workgroup that starts late -- because a collective's
- *                          kernel held its CU at the launch boundary -- is not the launch's tail.  (The zero-row skipping
- *                          backward always uses the counter.)
+ *                          1 (default) = from a device counter, so that a workgroup that starts late -- because a
+ *                          collective's kernel held its CU at the launch boundary -- is not the launch's tail.  (The
+ *                          zero-row skipping backward always uses the counter.)
  *   PXO_TUNE_WGRAD_RANGES  row ranges (split-K slabs) per layer of the 256x256 weight-gradient products: 0 = built-in
  *                          choice by pass size, n = exactly n (1 .. number of CUs). */
 #define PXO_TUNE_TILE_SCHED 0

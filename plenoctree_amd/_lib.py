@@ -104,7 +104,7 @@ SIGNATURES = {
     "pxo_uniform": (c_int, [c_uint64, c_uint64, c_int64, c_float, c_float, P, P]),
     "pxo_randint": (c_int, [c_uint64, c_uint64, c_int64, c_int64, P, P]),
     "pxo_generate_rays": (c_int, [P, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
-    "pxo_sample_batch": (c_int, [c_uint64, c_uint64, P, c_int, c_int, c_float, P, c_int64, P, P, P, P, P, P]),
+    "pxo_sample_batch": (c_int, [c_uint64, c_uint64, P, c_int, c_int, c_float, P, c_int64, c_int64, P, P, P, P, P, P]),
     "pxo_generate_rays_multi": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, P, P, P, P]),
     "pxo_mean_over_samples": (c_int, [CFG, P, P, c_int64, c_int, P, P]),
     "pxo_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_int64, c_float, P]),

@@ -44,7 +44,9 @@ int num_cus() {
 }
 
 // run-time choices between implementations of the same result (pxo_set_tuning)
-static int g_tune_tile_sched = 0;
+// tile schedule: the device counter by default (r05b: 3.548 vs 3.556 ms per step at 512 rays, 23.78 vs 23.84 at 4096 in one
+// process, profiles/r05b_tune_ab.jsonl; and a workgroup that starts late is not the launch's tail, r05b_contention_probe.jsonl)
+static int g_tune_tile_sched = 1;
 static int g_tune_wgrad_ranges = 0;
 static int g_tune_wgrad_skinny_ranges = 0;
 int tune_tile_sched() { return g_tune_tile_sched; }
@@ -446,13 +448,14 @@ int pxo_generate_rays(const float* c2w, int W, int H, float focal, const int64_t
 }
 
 int pxo_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal, const float* image_rgb,
-                     int64_t B, int64_t* pixel_ids, float* origins, float* directions, float* viewdirs, float* pixels,
-                     void* stream) {
+                     int64_t B, int64_t first, int64_t* pixel_ids, float* origins, float* directions, float* viewdirs,
+                     float* pixels, void* stream) {
   if (B == 0) return PXO_OK;
-  PXO_REQUIRE(B >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && image_rgb && origins && directions && viewdirs && pixels,
+  PXO_REQUIRE(B >= 0 && first >= 0 && W >= 1 && H >= 1 && focal > 0.f && c2w && image_rgb && origins && directions &&
+                  viewdirs && pixels,
               "pxo_sample_batch: bad arguments");
-  return launch_sample_batch(seed, stream_id, c2w, W, H, focal, image_rgb, B, pixel_ids, origins, directions, viewdirs, pixels,
-                             (hipStream_t)stream);
+  return launch_sample_batch(seed, stream_id, c2w, W, H, focal, image_rgb, B, first, pixel_ids, origins, directions, viewdirs,
+                             pixels, (hipStream_t)stream);
 }
 
 int pxo_generate_rays_multi(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* ray_ids, int64_t B,

@@ -199,7 +199,7 @@ int launch_sample_pdf(const float* z_c, const float* w_c, const float* o, const 
 int launch_generate_rays(const float* c2w, int n_cams, int W, int H, float focal, const int64_t* pix, int64_t B,
                          float* o, float* d, float* v, hipStream_t s);
 int launch_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal, const float* image,
-                        int64_t B, int64_t* ids, float* o, float* d, float* v, float* pixels, hipStream_t s);
+                        int64_t B, int64_t first, int64_t* ids, float* o, float* d, float* v, float* pixels, hipStream_t s);
 int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, int64_t* out, hipStream_t s);
 int launch_mean_samples(const float* raw_rgb, const float* raw_sigma, int64_t n_cells, int S, int C, float* out,
                         hipStream_t s);

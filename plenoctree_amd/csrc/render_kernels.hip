@@ -664,12 +664,13 @@ int launch_randint(uint64_t seed, uint64_t stream_id, int64_t count, int64_t n, 
 // (element i = 64-bit pair i % 2 of Philox block i / 2, mod W*H), the rays of generate_rays_kernel and the gather of the
 // image's colours -- the same arithmetic as the three separate launches, bit for bit.
 __global__ void sample_batch_kernel(uint64_t seed, uint64_t stream_id, const float* __restrict__ c2w, int W, int H, float focal,
-                                    const float* __restrict__ image, int64_t B, int64_t* __restrict__ ids,
+                                    const float* __restrict__ image, int64_t B, int64_t first, int64_t* __restrict__ ids,
                                     float* __restrict__ o, float* __restrict__ d, float* __restrict__ v,
                                     float* __restrict__ pixels) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
-  const int64_t q = i >> 1;
+  const int64_t e = first + i;            // element of the stream: output row i is element first + i of the global draw
+  const int64_t q = e >> 1;
   uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -677,7 +678,7 @@ __global__ void sample_batch_kernel(uint64_t seed, uint64_t stream_id, const flo
     philox_round(c, k0, k1);
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  const int h = (int)(i & 1);
+  const int h = (int)(e & 1);
   const uint64_t r64 = ((uint64_t)(h ? c[2] : c[0]) << 32) | (h ? c[3] : c[1]);
   const int64_t p = (int64_t)(r64 % (uint64_t)((int64_t)W * H));
   if (ids) ids[i] = p;
@@ -687,10 +688,10 @@ __global__ void sample_batch_kernel(uint64_t seed, uint64_t stream_id, const flo
 }
 
 int launch_sample_batch(uint64_t seed, uint64_t stream_id, const float* c2w, int W, int H, float focal, const float* image,
-                        int64_t B, int64_t* ids, float* o, float* d, float* v, float* pixels, hipStream_t s) {
+                        int64_t B, int64_t first, int64_t* ids, float* o, float* d, float* v, float* pixels, hipStream_t s) {
   if (B == 0) return PXO_OK;
   hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, seed, stream_id, c2w, W, H, focal,
-                     image, B, ids, o, d, v, pixels);
+                     image, B, first, ids, o, d, v, pixels);
   return check_launch("sample_batch");
 }
 

@@ -97,17 +97,24 @@ class HipFeeder:
     def generate_rays_multi(self, c2w_all, w, h, focal, ray_ids):
         return self.ops.generate_rays_multi(c2w_all, w, h, focal, ray_ids)
 
-    def sample_batch(self, seed, draw, count, c2w, w, h, focal, image_rgb):
+    def sample_batch(self, seed, draw, count, c2w, w, h, focal, image_rgb, first=0):
         """randint + generate_rays + the gather of the image's colours in one launch (pxo_sample_batch): the same values as
-        the three calls above, bit for bit."""
-        return self.ops.sample_batch(seed, draw, c2w, w, h, focal, image_rgb, count)
+        the three calls above, bit for bit.  `first`: rows = elements first .. first + count - 1 of the draw."""
+        return self.ops.sample_batch(seed, draw, c2w, w, h, focal, image_rgb, count, first=first)
 
 
 class Dataset:
     """Iterator yielding {"pixels": [B,3], "rays": Rays([B,3] x3)} on `device`."""
     feeder_factory = HipFeeder
 
-    def __init__(self, split, args, device, batch_size=None, seed=20201473):
+    def __init__(self, split, args, device, batch_size=None, seed=20201473, shard=None):
+        # shard = (rank, world): the reference's SINGLE-HOST step -- one image per step for the whole host, its global batch
+        # of pixels drawn once and cut into `world` contiguous pieces (datasets.py:159-166 + utils.shard, utils.py:518-522).
+        # Every rank then carries the same `seed` (same image sequence, same pixel draw) and `batch_size` is the rank's piece.
+        # Without it each rank is its own host (seed + host_id, train.py:128): its own image, its own pixels.
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        if self.shard is not None and not (0 <= self.shard[0] < self.shard[1]):
+            raise ValueError(f"shard {shard}: rank must be in [0, world)")
         self.split = split
         self.device = device
         self.feeder = type(self).feeder_factory(device)
@@ -142,17 +149,23 @@ class Dataset:
 
     def __next__(self):
         if self.split == "train" and self.image_batching:
+            if self.shard is not None:
+                raise ValueError("shard=(rank, world) is the single-image sampler's option (image_batching draws from all images)")
             return self._next_train_all_images()
         if self.split == "train":
             # datasets.py:159-166: one random image, batch_size random pixels (with replacement)
             image_index = int(self.rng.randint(0, self.n_examples))
             self.draws += 1
+            rank, world = self.shard if self.shard is not None else (0, 1)
+            first = rank * self.batch_size
             if getattr(self, "images", None) is not None and hasattr(self.feeder, "sample_batch"):
                 # resident images on the device: ids, rays and colours in one launch
                 o, d, v, px = self.feeder.sample_batch(self.seed, self.draws, self.batch_size, self._c2w_dev[image_index],
-                                                       self.w, self.h, self.focal, self.images[image_index])
+                                                       self.w, self.h, self.focal, self.images[image_index], first=first)
                 return {"pixels": px, "rays": utils.Rays(o, d, v)}
-            ray_indices = self.feeder.randint(self.seed, self.draws, self.batch_size, self.h * self.w)
+            ray_indices = self.feeder.randint(self.seed, self.draws, self.batch_size * world, self.h * self.w)
+            if world > 1:
+                ray_indices = ray_indices[first:first + self.batch_size].contiguous()
             rays = self._rays_for(image_index, ray_indices)
             return {"pixels": self._pixels_for(image_index, ray_indices, rays), "rays": rays}
         idx = self.it
@@ -296,7 +309,7 @@ class NSVF(Dataset):
 dataset_dict = {"blender": Blender, "nsvf": NSVF, "synthetic": Synthetic}
 
 
-def get_dataset(split, args, device, batch_size=None):
+def get_dataset(split, args, device, batch_size=None, seed=20201473, shard=None):
     if args.dataset not in dataset_dict:
         raise NotImplementedError(f"dataset {args.dataset} is not built on the MI355X path")
-    return dataset_dict[args.dataset](split, args, device, batch_size=batch_size)
+    return dataset_dict[args.dataset](split, args, device, batch_size=batch_size, seed=seed, shard=shard)

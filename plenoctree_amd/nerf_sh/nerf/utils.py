@@ -52,6 +52,10 @@ def define_flags(parser=None):
     # not a reference flag: leave sample rows whose upstream gradient is exactly zero (empty space, occluded samples,
     # background rays) out of the reverse pass -- bit-identical gradients, faster steps once the scene has empty space
     a("--skip_zero_rows", type=_bool, default=True)
+    # not a reference flag: with N ranks on one node, sample like the reference on ONE host with N local devices -- one image
+    # per step, its batch_size pixels drawn once and sharded over the ranks (datasets.py:159-166 + utils.shard) -- instead of
+    # like N hosts (each rank its own image).  N x (batch_size / N) then replays the 1 x batch_size batches exactly.
+    a("--per_host_image", type=_bool, default=False)
     a("--skip_layer", type=int, default=4)
     a("--num_rgb_channels", type=int, default=3)
     a("--num_sigma_channels", type=int, default=1)

@@ -39,9 +39,14 @@ def main(argv=None):
     write_ts_now(0)
 
     per_rank = args.batch_size // comm.world
-    dataset = datasets.get_dataset("train", args, device, batch_size=per_rank)
-    dataset.rng = np.random.RandomState(20201473 + comm.rank)      # train.py:128
-    dataset.seed = 20201473 + comm.rank
+    if args.per_host_image and not args.image_batching:
+        # the reference on ONE host with N local devices: one image per step, its batch_size pixels drawn once and sharded
+        # (datasets.py:159-166, utils.py:518-522); every rank carries host 0's seed and takes its contiguous piece of the draw
+        dataset = datasets.get_dataset("train", args, device, batch_size=per_rank, seed=20201473,
+                                       shard=(comm.rank, comm.world))
+    else:
+        # every rank its own host (np.random.seed(20201473 + jax.host_id()), train.py:128): its own image, its own pixels
+        dataset = datasets.get_dataset("train", args, device, batch_size=per_rank, seed=20201473 + comm.rank)
     test_dataset = datasets.get_dataset("test", args, device)
     model, state = models.get_model_state(args, device, restore=True)
     init_step = state.step + 1                                       # train.py:176

@@ -417,14 +417,15 @@ def generate_rays(c2w, W, H, focal, pixel_ids=None, count=None):
     return o, d, v
 
 
-def sample_batch(seed, stream_id, c2w, W, H, focal, image_rgb, B, want_ids=False):
-    """One training batch of one image in one launch: (origins, directions, viewdirs, pixels[, pixel_ids])."""
+def sample_batch(seed, stream_id, c2w, W, H, focal, image_rgb, B, want_ids=False, first=0):
+    """One training batch of one image in one launch: (origins, directions, viewdirs, pixels[, pixel_ids]); `first`: the B rows
+    are elements first .. first + B - 1 of the stream (a rank's shard of one global draw)."""
     _require_gpu()
     c2w = c2w[:3, :4].contiguous()
     dev = c2w.device
     o, d, v, px = _new(B, 3, device=dev), _new(B, 3, device=dev), _new(B, 3, device=dev), _new(B, 3, device=dev)
     ids = _new(B, device=dev, dtype=torch.int64) if want_ids else None
-    check(_lib.load().pxo_sample_batch(seed, stream_id, _f(c2w), W, H, float(focal), _f(image_rgb), B, _p(ids), _f(o), _f(d),
+    check(_lib.load().pxo_sample_batch(seed, stream_id, _f(c2w), W, H, float(focal), _f(image_rgb), B, int(first), _p(ids), _f(o), _f(d),
                                        _f(v), _f(px), _stream()), "pxo_sample_batch")
     return (o, d, v, px, ids) if want_ids else (o, d, v, px)
 

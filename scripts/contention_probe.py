@@ -7,11 +7,12 @@ workgroups that lives for 30-50 us on RCCL's high-priority stream; it starts at 
 level.  This probe puts exactly that beside the step: pxo_occupy_cus(k workgroups x 256 threads, 50 us) launched on the
 exchange stream through dist.GradReducer's `all_reduce` hook (bucket 0 only; bucket 1 is exposed at the end of the step by
 construction and is left empty here), for k in {0 (stream fork/join only), 8, 16, 32, 64}, at 512 and 4096 rays per step, with
-the static tile stride and with the device tile counter (PXO_TUNE_TILE_SCHED).  Printed: ms per step, and the slowdown against
-k = 0 -- to be compared with the probe's own 50 us.
+the static tile stride and with the device tile counter (PXO_TUNE_TILE_SCHED).  Variants are interleaved over several rounds; printed: median ms per step and
+the slowdown against k = 0 -- to be compared with the probe's own 50 us.
 """
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,7 +29,9 @@ def main():
     torch.cuda.set_device(0)
     side = pdist.exchange_stream(dev)            # before the first kernel (profiles/r04h_late_group.txt)
     micros = float(os.environ.get("PROBE_US", "50"))
-    steps = int(os.environ.get("PROBE_STEPS", "60"))
+    steps = int(os.environ.get("PROBE_STEPS", "40"))
+    rounds = int(os.environ.get("PROBE_ROUNDS", "5"))
+    default_sched = ops.get_tuning(ops.TUNE_TILE_SCHED)
     a = bench.parse(["--no-extras"])
     out = []
     for B in (512, 4096):
@@ -36,37 +39,45 @@ def main():
         model, params = models.construct_nerf(args, dev)
         state = models.TrainState(model.cfg, params)
         ds = datasets.Synthetic("train", args, dev, batch_size=B)
-        for sched in (0, 1):
-            ops.set_tuning(ops.TUNE_TILE_SCHED, sched)
-            base = None
-            for k in (0, 8, 16, 32, 64):
-                n0 = state.bucket0.numel()
+        n0 = state.bucket0.numel()
+        step = [0]
 
-                def fake_all_reduce(t, k=k, n0=n0):
-                    if k > 0 and t.numel() == n0:        # bucket 0, on the side stream (current inside GradReducer.reduce)
-                        ops.occupy_cus(k, 256, micros)
-                red = pdist.GradReducer(pdist.Comm(1, 0, 0, None), dev, all_reduce=fake_all_reduce)
+        def reducer_for(k):
+            def fake_all_reduce(t):
+                if k > 0 and t.numel() == n0:        # bucket 0, on the side stream (current inside GradReducer.reduce)
+                    ops.occupy_cus(k, 256, micros)
+            return pdist.GradReducer(pdist.Comm(1, 0, 0, None), dev, all_reduce=fake_all_reduce)
 
-                def run(n, first):
-                    for s_ in range(first, first + n):
-                        lr = utils.learning_rate_decay(s_, args.lr_init, args.lr_final, args.max_steps)
-                        models.train_step(model, state, next(ds), lr, randomized=True, seed=s_ << 8, world_size=1, reducer=red)
-                run(5, 0)
-                torch.cuda.synchronize()
-                best = None
-                for rep in range(3):
-                    t0 = time.perf_counter()
-                    run(steps, 5 + rep * steps)
+        def run(n, red):
+            for _ in range(n):
+                s_ = step[0]; step[0] += 1
+                lr = utils.learning_rate_decay(s_, args.lr_init, args.lr_final, args.max_steps)
+                models.train_step(model, state, next(ds), lr, randomized=True, seed=s_ << 8, world_size=1, reducer=red)
+
+        ks = (0, 8, 16, 32, 64)
+        reds = {k: reducer_for(k) for k in ks}
+        run(5, reds[0])
+        times = {(sched, k): [] for sched in (0, 1) for k in ks}
+        for _ in range(rounds):                       # interleaved: box drift hits every variant alike
+            for sched in (0, 1):
+                ops.set_tuning(ops.TUNE_TILE_SCHED, sched)
+                for k in ks:
+                    run(3, reds[k])
                     torch.cuda.synchronize()
-                    ms = 1e3 * (time.perf_counter() - t0) / steps
-                    best = ms if best is None else min(best, ms)
-                if k == 0:
-                    base = best
+                    t0 = time.perf_counter()
+                    run(steps, reds[k])
+                    torch.cuda.synchronize()
+                    times[(sched, k)].append(1e3 * (time.perf_counter() - t0) / steps)
+        for sched in (0, 1):
+            base = statistics.median(times[(sched, 0)])
+            for k in ks:
+                med = statistics.median(times[(sched, k)])
                 rec = {"rays": B, "tile_sched": "counter" if sched else "static", "probe_workgroups": k, "probe_us": micros,
-                       "ms_per_step": round(best, 4), "slowdown_us": round(1e3 * (best - base), 1)}
+                       "median_ms_per_step": round(med, 4), "slowdown_us": round(1e3 * (med - base), 1),
+                       "runs_ms": [round(x, 4) for x in times[(sched, k)]]}
                 out.append(rec)
                 print(json.dumps(rec), flush=True)
-    ops.set_tuning(ops.TUNE_TILE_SCHED, 0)
+    ops.set_tuning(ops.TUNE_TILE_SCHED, default_sched)
 
 
 if __name__ == "__main__":

@@ -1188,6 +1188,7 @@ def test_tile_counter_schedule_is_bit_identical(B):
     ops = _ops(); dev = _gpu()
     cfg = O.Cfg(sparsity_npoints=777)
     flat = make_params(cfg)
+    default = ops.get_tuning(ops.TUNE_TILE_SCHED)
     try:
         ops.set_tuning(ops.TUNE_TILE_SCHED, 0)
         g0, s0, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)
@@ -1197,7 +1198,7 @@ def test_tile_counter_schedule_is_bit_identical(B):
         g2, s2, _, _ = _one_train_step(ops, dev, cfg, flat, B, 1)
         g3, s3, _, _ = _one_train_step(ops, dev, cfg, flat, B, 0)       # again: the counters are re-zeroed by every step
     finally:
-        ops.set_tuning(ops.TUNE_TILE_SCHED, 0)
+        ops.set_tuning(ops.TUNE_TILE_SCHED, default)
     assert bool(torch.isfinite(g0).all())
     for g, s_ in ((g1, s1), (g2, s2), (g3, s3)):
         assert torch.equal(g0, g) and torch.equal(s0, s_)
@@ -1233,6 +1234,23 @@ def test_wgrad_ranges_tuning_and_long_ranges_in_skipping_mode():
     for knob, bad in ((ops.TUNE_TILE_SCHED, 2), (ops.TUNE_WGRAD_RANGES, -1), (ops.TUNE_WGRAD_RANGES, 100000), (99, 0)):
         with pytest.raises(Exception, match="pxo_set_tuning"):
             ops.set_tuning(knob, bad)
+
+
+def test_per_host_image_shards_on_the_device():
+    """datasets shard=(rank, world) through the fused launch (pxo_sample_batch's `first`): 8 x 512 rays = the 1 x 4096 batch,
+    bit for bit, over several steps -- the reference's single-host sampler (datasets.py:159-166 + utils.shard)."""
+    _ops(); dev = _gpu()
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
+    utils.update_flags(args); args.factor = 8
+    whole = datasets.get_dataset("train", args, dev, batch_size=4096, seed=20201473)
+    shards = [datasets.get_dataset("train", args, dev, batch_size=512, seed=20201473, shard=(r, 8)) for r in range(8)]
+    for _ in range(3):
+        want = next(whole)
+        got = [next(d) for d in shards]
+        assert torch.equal(torch.cat([g["pixels"] for g in got]), want["pixels"])
+        for k in range(3):
+            assert torch.equal(torch.cat([g["rays"][k] for g in got]), want["rays"][k])
 
 
 def test_sample_batch_equals_the_three_separate_launches():

@@ -14,8 +14,11 @@ inverse-CDF sampling.
                                          the float64 oracle's render of the SAME weights: |dPSNR| <= 1e-4 dB
 
 Bounds, fixed numbers:
-  Stats      rtol 2e-5 against the float64 oracle (loss_sp 5e-3: 1 - mean(exp(-0.05 relu(sigma))) of a mostly empty volume is
-             a difference of nearly equal numbers in float32; same bar as L1 in tests/test_gpu_reference_fixtures.py)
+  Stats      against the float64 oracle: rtol 2e-5, or within STATS_FACTOR x the distance of the oracle's own float32
+             evaluation from its float64 one (with random u the fine samples of a float32 and a float64 evaluation differ in
+             the bins next to empty stretches of the cdf: the fine loss of this batch moves by 4e-5 relative either way);
+             loss_sp 5e-3 (1 - mean(exp(-0.05 relu(sigma))) of a mostly empty volume is a difference of nearly equal numbers
+             in float32; same bar as L1 in tests/test_gpu_reference_fixtures.py)
   gradient   relative L2 error per MLP against the float64 oracle <= GRAD_FACTOR x the distance of the oracle's OWN float32
              evaluation from its float64 one (the bound G1 uses: the float32 noise floor of this function at this state),
              and never looser than GRAD_CAP
@@ -29,12 +32,13 @@ import pytest
 import torch
 
 from oracle import nerf_oracle as O
-from _helpers import _gpu, _ops, _psnr, close, oracle_loss_and_grad_chunked, oracle_render_chunked
+from _helpers import _gpu, _ops, _psnr, oracle_loss_and_grad_chunked, oracle_render_chunked
 
 pytestmark = pytest.mark.gpu
 
 TRAIN_STEPS, RAYS = 2000, 4096
 GRAD_FACTOR, GRAD_CAP = 2.0, 1e-2
+STATS_FACTOR = 2.0
 
 
 def _record(name, **kv):
@@ -105,9 +109,11 @@ def test_trained_step_matches_f64_oracle(trained):
     st32, g32 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float32)
     st64, g64 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float64)
     t_cpu = time.time() - tc
-    rec = dict(live_chunk_fraction=l1 / t1_, oracle_s=t_cpu, psnr_batch_f64=st64["psnr"], psnr_batch_hip=float(s0[1]))
+    rec = dict(live_chunk_fraction=l1 / t1_, oracle_s=t_cpu, psnr_batch_f64=st64["psnr"], psnr_batch_f32=st32["psnr"],
+               psnr_batch_hip=float(s0[1]))
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
         rec[f"stats_{k}_rel"] = abs(float(s0[i]) - st64[k]) / max(abs(st64[k]), 1e-30)
+        rec[f"stats_{k}_rel_f32_oracle"] = abs(st32[k] - st64[k]) / max(abs(st64[k]), 1e-30)
     g_hip = g0.double()
     errs = []
     for mi, (lo, hi) in enumerate(((0, n), (n, 2 * n))):
@@ -121,7 +127,8 @@ def test_trained_step_matches_f64_oracle(trained):
     print("trained step:", json.dumps(rec))
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
         rtol = 5e-3 if k == "loss_sp" else 2e-5
-        close(f"stats/{k} (f64 oracle)", s0[i], torch.tensor(st64[k]), rtol=rtol, atol=1e-7)
+        tol = max(rtol * abs(st64[k]), STATS_FACTOR * abs(st32[k] - st64[k]), 1e-7)
+        assert abs(float(s0[i]) - st64[k]) <= tol, (k, float(s0[i]), st64[k], st32[k], tol)
     for mi, e_hip, e_cpu in errs:
         bound = min(max(GRAD_FACTOR * e_cpu, 1e-3), GRAD_CAP)
         assert e_hip <= bound, f"MLP_{mi}: rel L2 err vs f64 oracle {e_hip:.3g} > {bound:.3g} (CPU f32 oracle: {e_cpu:.3g})"

@@ -78,6 +78,35 @@ def test_synthetic_dataset_batches():
         datasets.get_dataset("train", a, torch.device("cpu"))
 
 
+def test_per_host_image_shards_replay_the_single_device_batch():
+    """--per_host_image (datasets shard=(rank, world)): the reference on ONE host draws one image and batch_size pixel ids per
+    step and shards them over its local devices (nerf_sh/nerf/datasets.py:159-166 + utils.shard, utils.py:518-522).  8 ranks of
+    512 rays must replay the 1 x 4096 batches exactly, step after step; without the option every rank is its own host and
+    draws its own image (train.py:128)."""
+    a = _args(["--config", "blender", "--train_dir", "x", "--dataset", "synthetic"])
+    utils.update_flags(a); a.dataset = "synthetic"; a.factor = 8
+    cpu = torch.device("cpu")
+    whole = datasets.get_dataset("train", a, cpu, batch_size=4096, seed=20201473)
+    shards = [datasets.get_dataset("train", a, cpu, batch_size=512, seed=20201473, shard=(r, 8)) for r in range(8)]
+    for _ in range(3):
+        want = next(whole)
+        got = [next(d) for d in shards]
+        assert torch.equal(torch.cat([g["pixels"] for g in got]), want["pixels"])
+        for k in range(3):
+            assert torch.equal(torch.cat([g["rays"][k] for g in got]), want["rays"][k])
+    # the reference's pieces are utils.shard's: [n_devices, B / n_devices] in row order
+    assert torch.equal(utils.shard(want["pixels"], 8, 5), got[5]["pixels"])
+    # default sampler: rank r is host r
+    own = [datasets.get_dataset("train", a, cpu, batch_size=512, seed=20201473 + r) for r in range(2)]
+    b0, b1 = next(own[0]), next(own[1])
+    assert not torch.equal(b0["rays"].origins, b1["rays"].origins)            # different images
+    with pytest.raises(ValueError):
+        datasets.get_dataset("train", a, cpu, batch_size=512, shard=(8, 8))
+    a.image_batching = True
+    with pytest.raises(ValueError):
+        next(datasets.get_dataset("train", a, cpu, batch_size=512, shard=(0, 8)))
+
+
 def test_blender_loader(tmp_path):
     from PIL import Image
     import json

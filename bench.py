@@ -13,7 +13,7 @@ MLP_1's half + stats at the end), Adam + weight re-pack.  Rank 0 prints ONE JSON
 carries records of the other BASELINE configs and of the metric's second half:
 `converge` (eval PSNR on held-out 800x800 views after a fixed training budget), `strong512` (configs[2] strong-scaling
 shape), `tt_sh25` (configs[3] shape), `coarse64` (configs[0] shape: 64 coarse samples only), `render_fwd` (the eval
-path) and `grid512` (configs[4]).
+path), `grid512` (configs[4]) and `octree` (the PlenOctree-side kernels with their HBM rooflines).
 
 `--backend gloo` is a DRY RUN of this file's multi-rank control flow on CPU ranks for tests/test_bench_dry_run_cpu.py,
 which installs oracle-backed stand-ins for the HIP entry points first (the product has no CPU path: without the
@@ -39,7 +39,7 @@ FLOP_TRAIN_PER_RAY_COARSE_ONLY = {3: 189.2e6, 4: 191.9e6}
 FLOP_RENDER_PER_RAY = {3: 257.8e6, 4: 261.4e6}
 FLOP_SIGMA_PER_POINT = 982528                        # trunk + sigma head only (131.9 TFLOP at 512^3)
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "bf16x3", "coarse64", "tt_sh25")
+ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "octree", "bf16x3", "coarse64", "tt_sh25")
 
 
 def parse(argv=None):
@@ -63,12 +63,15 @@ def parse(argv=None):
                         "(datasets shard=(rank, world)); default: every rank its own image (the reference's multi-host sampler)")
     p.add_argument("--tune", default="", help="A/B only: pxo_set_tuning knobs, e.g. tile_sched=1,wgrad_ranges=73,wgrad_skinny_ranges=128 "
                                               "(same results, different schedule; recorded in the line as `tuning`)")
-    p.add_argument("--cpu-rays", type=int, default=512, help="rays in the bounded CPU-baseline sample")
-    p.add_argument("--cpu-steps", type=int, default=8)
+    p.add_argument("--cpu-rays", type=int, default=1024, help="rays per step of the CPU baseline (BASELINE.md section 3: 1024)")
+    p.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the CPU baseline (after --cpu-warmup)")
+    p.add_argument("--cpu-warmup", type=int, default=3)
+    p.add_argument("--cpu-full", action="store_true", help="CPU baseline also at B = 4096 (configs[1]; ~3 minutes of CPU)")
     p.add_argument("--converge-steps", type=int, default=2000, help="training budget of the `converge` record")
     p.add_argument("--converge-views", type=int, default=2, help="held-out 800x800 views rendered for eval PSNR")
     # sizes of the other records; the defaults are the BASELINE configs, the dry run passes small ones
     p.add_argument("--strong-rays", type=int, default=512)
+    p.add_argument("--octree-cams", type=int, default=4, help="views of the `octree` record (scripts/octree_bench.py uses 8)")
     p.add_argument("--grid-reso", type=int, default=512)
     p.add_argument("--eval-step", type=int, default=105,
                    help="render_fwd / grid512 are evaluated on the parameters after exactly this many train steps")
@@ -117,59 +120,90 @@ def flags_for(a, preset, batch, **over):
     return args
 
 
-def cpu_baseline(a, args_ns, n_rays, n_steps, device):
-    """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores
-    on a bounded sample of the same workload: `n_rays` rays x (64+128) samples + 10k sparsity
-    points, forward + backward + Adam, float32, torch CPU threads = all cores."""
+def cpu_baseline(a, args_ns, device):
+    """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores by BASELINE.md section 3's protocol:
+    3 warm-up + 10 timed train steps (forward + backward + Adam, float32), rays/s = B x steps/s (nerf_sh/train.py:224), at
+    configs[0]'s shapes -- B = 1024 with 64 coarse samples only and with 64 + 128 samples (+ 10k sparsity points) -- and, with
+    --cpu-full, configs[1]'s B = 4096 (3 minutes of CPU; left out of the default run, which must stay within a few minutes).
+    `value` is the 64 + 128 figure.  Thread count: torch's intra-op pool oversubscribes badly on many-core hosts, so a 32-ray
+    probe picks among a few candidates; the count actually used is reported next to nproc."""
+    import platform
     from oracle import nerf_oracle as O
     from plenoctree_amd.nerf_sh.nerf import datasets
-    cfg = O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far, sparsity_npoints=args_ns.sparsity_npoints,
-                sparsity_length=args_ns.sparsity_length, sparsity_radius=args_ns.sparsity_radius)
     gen = torch.Generator().manual_seed(0)
-    # the same feeder as the GPU legs (batches are drawn on the device and copied to the host before the clock starts)
-    ds_dev = datasets.Synthetic("train", args_ns, device, batch_size=n_rays)
 
-    class _HostBatches:
-        def __next__(self):
-            b = next(ds_dev)
-            return {"rays": type(b["rays"])(*[t.cpu() for t in b["rays"]]), "pixels": b["pixels"].cpu()}
-    ds = _HostBatches()
+    def cfg_for(fine):
+        return O.Cfg(sh_deg=args_ns.sh_deg, near=args_ns.near, far=args_ns.far, sparsity_npoints=args_ns.sparsity_npoints,
+                     sparsity_length=args_ns.sparsity_length, sparsity_radius=args_ns.sparsity_radius,
+                     num_fine_samples=128 if fine else 0)
 
-    def step_once(flat, m, v, step, batch):
+    def host_batches(n_rays):
+        # the same feeder as the GPU legs (batches are drawn on the device and copied to the host before the clock starts)
+        ds_dev = datasets.Synthetic("train", args_ns, device, batch_size=n_rays)
+
+        class _HostBatches:
+            def __next__(self):
+                b = next(ds_dev)
+                return {"rays": type(b["rays"])(*[t.cpu() for t in b["rays"]]), "pixels": b["pixels"].cpu()}
+        return _HostBatches()
+
+    def step_once(cfg, flat, m, v, step, batch):
         rays = O.Rays(*batch["rays"])
         n = rays.origins.shape[0]
-        t_rand = torch.rand(n, 64, generator=gen); u = torch.rand(n, 128, generator=gen)
+        t_rand = torch.rand(n, 64, generator=gen)
+        u = torch.rand(n, 128, generator=gen) if cfg.num_fine_samples > 0 else None
         sp = (torch.rand(cfg.sparsity_npoints, 3, generator=gen) * 2 - 1) * cfg.sparsity_radius
         t0 = time.perf_counter()
         out = O.train_step(flat, m, v, step, rays, batch["pixels"], cfg, t_rand, u, sp, 5e-4)
         return out[:3], time.perf_counter() - t0
 
+    ncpu = os.cpu_count() or 1
+    cfg = cfg_for(True)
     flat = O.flatten_params(O.init_params(cfg))
     m = torch.zeros_like(flat); v = torch.zeros_like(flat)
-    # give the CPU its best thread count: torch's intra-op pool oversubscribes badly on many-core
-    # hosts, so a 32-ray probe picks among a few candidates (each probe ~1 s)
-    ncpu = os.cpu_count() or 1
-    small = {k: (type(val)(*[t[:32] for t in val]) if k == "rays" else val[:32]) for k, val in next(ds).items()}
+    small = {k: (type(val)(*[t[:32] for t in val]) if k == "rays" else val[:32]) for k, val in next(host_batches(32)).items()}
     best, cores = None, 1
     for c in sorted({min(ncpu, x) for x in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(c)
-        step_once(flat, m, v, 0, small)
-        _, dt = step_once(flat, m, v, 0, small)
+        step_once(cfg, flat, m, v, 0, small)
+        _, dt = step_once(cfg, flat, m, v, 0, small)
         if best is None or dt < best:
             best, cores = dt, c
     torch.set_num_threads(cores)
-    times = []
-    for step in range(n_steps + 1):
-        (flat, m, v), dt = step_once(flat, m, v, step, next(ds))
-        if step > 0:                       # first step warms the allocator / thread pool
-            times.append(dt)
-        if sum(times) + dt > 45.0 and times:   # keep the default run within a few minutes
-            break
-    rps = n_rays * len(times) / sum(times)
-    return {"value": rps, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} train steps of {n_rays} rays x (64+128) samples + {cfg.sparsity_npoints} "
-                      f"sparsity points, oracle/nerf_oracle.py (torch-CPU f32 restatement, not JAX), "
-                      f"{sum(times):.1f} s on rank 0's host cores"}
+
+    def protocol(n_rays, fine, warm=a.cpu_warmup, timed=a.cpu_steps):
+        cfg = cfg_for(fine)
+        flat = O.flatten_params(O.init_params(cfg))
+        m = torch.zeros_like(flat); v = torch.zeros_like(flat)
+        ds = host_batches(n_rays)
+        times = []
+        for step in range(warm + timed):
+            (flat, m, v), dt = step_once(cfg, flat, m, v, step, next(ds))
+            if step >= warm:
+                times.append(dt)
+        return {"rays_per_step": n_rays, "samples": "64+128" if fine else "64", "warmup_steps": warm, "timed_steps": len(times),
+                "rays_per_s": n_rays * len(times) / sum(times), "s_per_step": sum(times) / len(times), "cpu_s": sum(times)}
+
+    shapes = [protocol(a.cpu_rays, False), protocol(a.cpu_rays, True)]
+    dropped = []
+    if a.cpu_full:
+        shapes.append(protocol(4096, True))
+    else:
+        dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: run with --cpu-full)")
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    head = shapes[1]
+    return {"value": head["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "nproc": ncpu, "cpu_model": cpu_model or platform.processor(), "torch_version": torch.__version__,
+            "threads_probed": cores, "protocol": f"BASELINE.md section 3: {a.cpu_warmup} warm-up + {a.cpu_steps} timed train steps, rays/s = B x steps/s",
+            "shapes": shapes, "shapes_dropped": dropped,
+            "sample": f"{head['timed_steps']} timed train steps (after {head['warmup_steps']} warm-up) of {head['rays_per_step']} rays x "
+                      f"(64+128) samples + {args_ns.sparsity_npoints} sparsity points, oracle/nerf_oracle.py (torch-CPU f32 "
+                      f"restatement, not JAX), {head['cpu_s']:.1f} s on rank 0's host cores"}
 
 
 def hbm_traffic(kernel):
@@ -518,6 +552,32 @@ def run_grid(job, tr, stages_after_grid=True):
             "tree_nodes": int(tree.n_internal), "sharding": f"x-slabs over {job.world} GPU(s) + all-gather"}
 
 
+def run_octree(job, a):
+    """SURVEY 8(f) rows 2-3 in the driver-run line: the PlenOctree-side kernels at the reference's sizes (512^3 grid, 800 x 800
+    views, SH16) on the analytic scene of scripts/octree_bench.py -- weight mask per camera (octree/extraction.py:181-214),
+    tree build, step-2 sampling (:369), VolumeRenderer.render_persp exact and early-stop per view (octree/optimization.py:195),
+    its backward per view (:216) and one SGD step over the tree -- each with its counted algorithmic bytes, the fraction of
+    6.3 TB/s (and of the 8 TB/s specification) they are moved at, and the HBM bytes of the committed PMC passes.  Every rank
+    measures its own GPU (nothing here is sharded); rank 0's numbers are reported."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import octree_bench
+    job.sync()
+    t0 = time.perf_counter()
+    m = octree_bench.measure(octree_bench.defaults(cams=a.octree_cams, reps=1))
+    job.sync()
+    keep = ("basis_dim", "reso", "image", "cams", "step_size", "grid_weight_render_ms_per_cam", "grid_weight_roofline", "mask_voxels",
+            "tree_build_ms", "n_internal", "sample_cells_ms", "sample_points", "render_exact_ms_per_image", "render_exact_roofline",
+            "render_fast_ms_per_image", "render_fast_roofline", "render_bwd_ms_per_image", "render_bwd_roofline",
+            "render_bwd_reusing_fwd_ms_per_image", "render_bwd_reusing_fwd_roofline", "sgd_ms", "sgd_roofline", "tree_data_MB")
+    rec = {k: m[k] for k in keep if k in m}
+    for k, v in rec.items():                      # the per-image work counts stay in profiles/*_octree_bench.json
+        if isinstance(v, dict) and "per_image" in v:
+            v.pop("per_image")
+    rec["wall_s"] = time.perf_counter() - t0
+    rec["scene"] = "scripts/octree_bench.py: three fuzzy spheres on the 512^3 grid, random SH16 leaves; same command as profiles/*_octree_bench.json"
+    return rec
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
@@ -566,6 +626,8 @@ def main(argv=None):
         extras["render_fwd"] = run_render(job, tr)
     if "grid512" in want:
         extras["grid512"] = run_grid(job, tr)
+    if "octree" in want and job.cuda:
+        extras["octree"] = run_octree(job, a)
     if "bf16x3" in want:
         # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
         twin = split_precision_twin(tr)
@@ -602,7 +664,7 @@ def main(argv=None):
     # the CPU baseline is timed on rank 0's host cores only, whatever the world size (the other ranks wait at the barrier)
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a, head["args"], a.cpu_rays, a.cpu_steps, job.device)
+        cpu = cpu_baseline(a, head["args"], job.device)
     if rank == 0:
         per_gpu, deg, kernels = head["per_gpu"], head["deg"], head["kernels"]
         elapsed = head["elapsed"]

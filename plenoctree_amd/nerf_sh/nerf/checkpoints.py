@@ -155,3 +155,49 @@ def restore_checkpoint(train_dir, state=None):
         return tree
     load_tree_into_state(tree, state)
     return path
+
+
+# ---- the reference's OTHER checkpoint format: a torch state dict of its torch twin ------------------------------------------
+def torch_state_dict_to_tree(sd, depth=8):
+    """`ckpt["model"]` of octree/nerf/models.py:52-63 (restore_model_state: `*.ckpt` files holding the state dict of the torch
+    NerfModel, whose Linear weights are [out, in]) as the flax params tree: the inverse of the key map the reference applies to
+    a flax checkpoint (octree/nerf/models.py:79-102: Dense_i -> input_layers.i for i < net_depth, then sigma_layer, then --
+    without view directions -- rgb_layer; kernel = weight.T)."""
+    names = [f"input_layers.{i}" for i in range(depth)] + ["sigma_layer", "rgb_layer"]
+    for k in sd:
+        if any(t in k for t in ("bottleneck_layer", "condition_layers", "sg_lambda", "sg_mu_spher")):
+            raise ValueError(f"torch checkpoint key {k!r}: the view-conditioned head / SG basis is not built on the MI355X path "
+                             "(use_viewdirs=false SH models only)")
+    tree = {}
+    for mi in range(2):
+        mlp = {}
+        for li, name in enumerate(names):
+            wk, bk = f"MLP_{mi}.{name}.weight", f"MLP_{mi}.{name}.bias"
+            if wk not in sd or bk not in sd:
+                raise ValueError(f"torch checkpoint has no {wk} / {bk}")
+            w = sd[wk].detach().cpu().numpy() if hasattr(sd[wk], "detach") else np.asarray(sd[wk])
+            b = sd[bk].detach().cpu().numpy() if hasattr(sd[bk], "detach") else np.asarray(sd[bk])
+            mlp[f"Dense_{li}"] = {"kernel": np.ascontiguousarray(w.T.astype(np.float32)), "bias": b.astype(np.float32)}
+        tree[f"MLP_{mi}"] = mlp
+    return tree
+
+
+def latest_torch_checkpoint(train_dir):
+    paths = sorted(glob.glob(os.path.join(train_dir, "*.ckpt")))       # octree/nerf/models.py:56-59: sorted, last one
+    return paths[-1] if paths else None
+
+
+def restore_torch_checkpoint(train_dir, state):
+    """restore_model_state (octree/nerf/models.py:52-63): the newest `*.ckpt` of train_dir into `state` (parameters only; a
+    state dict carries no optimizer moments).  Returns the path, or None when there is no such file."""
+    path = train_dir if os.path.isfile(train_dir) else latest_torch_checkpoint(train_dir)
+    if path is None:
+        return None
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(ckpt, dict) or "model" not in ckpt:
+        raise ValueError(f'{path}: not a checkpoint of the reference\'s torch twin (no "model" state dict)')
+    params = torch_state_dict_to_tree(ckpt["model"])
+    state.params.copy_(torch.from_numpy(tree_to_arena(params, state.cfg)).to(state.params.device))
+    state.m.zero_(); state.v.zero_()
+    state.repack()
+    return path

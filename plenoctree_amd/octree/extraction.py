@@ -234,6 +234,29 @@ def define_flags():
     return p
 
 
+def load_nerf_checkpoint(args, state):
+    """get_model_state(args, restore=True) of octree/nerf/models.py:38-49.  The reference reads one of two formats, chosen by
+    --is_jaxnerf_ckpt (:45): a flax-msgpack `checkpoint_<step>` of nerf_sh.train (restore_model_state_from_jaxnerf, :66-113) or
+    a torch state dict `*.ckpt` of its torch twin (restore_model_state, :52-63).  Both are read here.  Where the reference, with
+    no file of the chosen format in train_dir, silently goes on with the freshly initialised network, this raises -- except that
+    without the flag a train_dir holding only flax checkpoints (what nerf_sh.train here and the reference's JAX trainer write)
+    is read as such, and said so."""
+    from ..nerf_sh.nerf import checkpoints
+    if args.is_jaxnerf_ckpt:
+        path = checkpoints.restore_checkpoint(args.train_dir, state)
+        if path is None:
+            raise FileNotFoundError(f"--is_jaxnerf_ckpt: no flax checkpoint_<step> in {args.train_dir}")
+        return f"* restore ckpt from {path} (flax msgpack)"
+    path = checkpoints.restore_torch_checkpoint(args.train_dir, state)
+    if path is not None:
+        return f"* restore ckpt from {path}. (torch state dict)"
+    path = checkpoints.restore_checkpoint(args.train_dir, state)
+    if path is None:
+        raise FileNotFoundError(f"no *.ckpt (torch state dict) and no checkpoint_<step> (flax msgpack) in {args.train_dir}: "
+                                "nothing to extract from")
+    return f"* no *.ckpt in {args.train_dir}: restore ckpt from {path} (flax msgpack, as with --is_jaxnerf_ckpt)"
+
+
 def main(argv=None):
     args = define_flags().parse_args(argv)
     utils.update_flags(args)
@@ -245,10 +268,8 @@ def main(argv=None):
     utils.check_flags(args, require_data=True, world_size=comm.world)
     say = print if comm.rank == 0 else (lambda *a, **k: None)
     say("* Loading NeRF", flush=True)
-    # --is_jaxnerf_ckpt (:117-121, octree/nerf/models.py:45): the reference reads either a flax-msgpack checkpoint of
-    # nerf_sh.train or a torch state dict; this path always reads the former (what nerf_sh.train here and the reference's
-    # JAX trainer both write), so the flag is accepted and changes nothing.
-    model, state = models.get_model_state(args, device, restore=True)
+    model, state = models.get_model_state(args, device, restore=False)
+    say(load_nerf_checkpoint(args, state), flush=True)
     dataset = datasets.get_dataset("train", args, device)
     if args.bbox_from_data:                                  # :447-451 (NSVF datasets carry bbox.txt)
         bbox = getattr(dataset, "bbox", None)

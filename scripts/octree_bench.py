@@ -42,14 +42,37 @@ def timed(fn, reps=3):
     return a.elapsed_time(b) / reps
 
 
-PEAK_HBM_ACHIEVABLE_GBPS = 6300.0
+PEAK_HBM_ACHIEVABLE_GBPS = 6300.0        # MI355X_MICROARCH.md: what a streaming kernel reaches
+PEAK_HBM_SPEC_GBPS = 8000.0              # the HBM3E specification
 
 
-def roofline(alg_bytes, floor_bytes, ms, parts):
+def hbm_traffic(kernel):
+    """Measured HBM bytes per launch of `kernel` from the committed PMC passes of scripts/octree_bench.py
+    (profiles/octree_hbm_traffic.json, written by scripts/summarize_octree_prof.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "octree_hbm_traffic.json")) as f:
+            doc = json.load(f)
+        k = doc["kernels"][kernel]
+        return {"read_bytes": k["hbm_read_bytes_per_launch"], "write_bytes": k["hbm_write_bytes_per_launch"],
+                "source": "profiles/octree_hbm_traffic.json (" + doc.get("source", "rocprofv3 --pmc passes") + "); not measured inside this run"}
+    except Exception:
+        return None
+
+
+def roofline(alg_bytes, floor_bytes, ms, parts, kernel=None):
     gbps = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "algorithmic_bytes": alg_bytes, "hbm_floor_bytes": floor_bytes, "ms": ms, "achieved": gbps,
-            "peak": PEAK_HBM_ACHIEVABLE_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_ACHIEVABLE_GBPS,
-            "frac_of_hbm_floor": floor_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_ACHIEVABLE_GBPS, "per_image": parts}
+    r = {"bound": "hbm", "algorithmic_bytes": alg_bytes, "hbm_floor_bytes": floor_bytes, "ms": ms, "achieved": gbps,
+         "peak": PEAK_HBM_ACHIEVABLE_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_ACHIEVABLE_GBPS,
+         "frac_of_spec_8TBps": gbps / PEAK_HBM_SPEC_GBPS,
+         "frac_of_hbm_floor": floor_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_ACHIEVABLE_GBPS, "per_image": parts}
+    if kernel:
+        r["kernel"] = kernel
+        t = hbm_traffic(kernel)
+        if t:
+            r["traffic"] = t["read_bytes"] + t["write_bytes"]
+            r["traffic_over_floor"] = r["traffic"] / max(floor_bytes, 1)
+            r["traffic_detail"] = t
+    return r
 
 
 def main():
@@ -62,7 +85,20 @@ def main():
     p.add_argument("--gw-only", action="store_true", help="stop after grid_weight_render (A/B of that kernel)")
     p.add_argument("--hard", action="store_true", help="exact zeros outside the spheres (as a trained, relu'd density has) instead of fuzzy tails")
     p.add_argument("--no-roofline", action="store_true", help="skip the counting passes")
+    p.add_argument("--reps", type=int, default=2)
     a = p.parse_args()
+    print(json.dumps(measure(a)), flush=True)
+
+
+def defaults(**over):
+    """The argument namespace of `measure` for callers that are not this CLI (bench.py's `octree` record)."""
+    a = argparse.Namespace(depth=8, size=800, step=1e-4, cams=8, basis=16, gw_only=False, hard=False, no_roofline=False, reps=2)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def measure(a):
     from plenoctree_amd import build, octree_ops as oops
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
     from plenoctree_amd.octree.svox import N3Tree, VolumeRenderer
@@ -101,13 +137,12 @@ def main():
         # unbricking the weights stream the grid 4 times per call (amortised over the call's cameras)
         alg = per["samples"] * 4 + c["distinct_voxels"] * 8 / n + per["brick_passes_bytes"]
         floor = (min(c["distinct_voxels"] * 4 + c["distinct_voxels"] * 8, reso ** 3 * 12)) / n + per["brick_passes_bytes"]
-        out["grid_weight_roofline"] = roofline(alg, floor, ms / a.cams, per)
+        out["grid_weight_roofline"] = roofline(alg, floor, ms / a.cams, per, "grid_weight_pow2_kernel")
     mask = oops.threshold_mask(wt, 1e-3)
     out["mask_voxels"] = int(mask.sum())
     out["weight_sum"] = float(wt.double().sum())
     if a.gw_only:
-        print(json.dumps(out), flush=True)
-        return
+        return out
     t0 = time.perf_counter()
     child, pd, levels = oops.tree_from_mask(mask, depth)
     torch.cuda.synchronize()
@@ -132,7 +167,7 @@ def main():
             return [r.render_persp(c, width=W, height=H, fx=focal, fast=fast) for c in cams]
 
     for fast in (False, True):
-        ms = timed(lambda: render_all(fast), reps=2) / a.cams
+        ms = timed(lambda: render_all(fast), reps=a.reps) / a.cams
         key = "fast" if fast else "exact"
         out[f"render_{key}_ms_per_image"] = ms
         out[f"render_{key}_Mrays_per_s"] = W * H / ms / 1e3
@@ -143,7 +178,7 @@ def main():
             D = tree.data_dim
             alg = avg["shaded_samples"] * D * 4 + (avg["samples"] - avg["shaded_samples"]) * 4 + avg["child_loads"] * 4 + W * H * 12
             floor = avg["distinct_leaves"] * D * 4 + W * H * 12
-            out[f"render_{key}_roofline"] = roofline(alg, floor, ms, avg)
+            out[f"render_{key}_roofline"] = roofline(alg, floor, ms, avg, "octree_render_kernel" if not fast else None)
             counts[key] = (avg, alg, floor)
     with torch.no_grad():
         im = r.render_persp(cams[0], width=W, height=H, fx=focal)
@@ -159,7 +194,7 @@ def main():
             _, g = oops.image_mse(imc, gt)
             oops.octree_render_persp_bwd(tree.view(), c, W, H, focal, r._opts(False), g, grad, out_rgb=imc if reuse else None)
     for reuse in (False, True):
-        ms = timed(lambda: bwd(reuse), reps=2) / a.cams
+        ms = timed(lambda: bwd(reuse), reps=a.reps) / a.cams
         key = "render_bwd_reusing_fwd" if reuse else "render_bwd"
         out[f"{key}_ms_per_image"] = ms
         out[f"{key}_Mrays_per_s"] = W * H / ms / 1e3
@@ -171,11 +206,13 @@ def main():
             marches = 1 if reuse else 2
             extra = W * H * (24 if reuse else 12) + avg["distinct_leaves"] * D * 4 * 2
             out[f"{key}_roofline"] = roofline(marches * (alg_f - W * H * 12) + extra, floor_f - W * H * 12 + extra, ms,
-                                              dict(avg, marches=marches))
+                                              dict(avg, marches=marches), "octree_render_bwd4_kernel" if reuse else None)
     out["grad_abs_sum"] = float(grad.double().abs().sum())
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
     out["tree_data_MB"] = tree.data.numel() * 4 / 1e6
-    print(json.dumps(out), flush=True)
+    # SGD streams data + gradient in and data out: 12 B per float
+    out["sgd_roofline"] = roofline(tree.data.numel() * 12.0, tree.data.numel() * 12.0, out["sgd_ms"], {}, "sgd_kernel")
+    return out
 
 
 if __name__ == "__main__":

@@ -46,6 +46,23 @@ def main(src, dst_dir, tag):
     with open(os.path.join(dst_dir, f"{tag}_octree_kernels.md"), "w") as g:
         g.write("\n".join(out) + "\n")
     print("\n".join(out))
+    # machine-readable twin for bench.py's `octree` record (scripts/octree_bench.py hbm_traffic): short kernel name -> bytes
+    import json
+    import subprocess
+    doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py, session {tag}", "kernels": {}}
+    try:
+        doc["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)),
+                                                stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    for k, (calls, ms, pct) in stats.items():
+        if k in rd and k in wr:
+            short = k.split("pxo::")[-1].split("<")[0]
+            e = {"hbm_read_bytes_per_launch": rd[k] * 2 * 1024, "hbm_write_bytes_per_launch": wr[k] * 1024, "avg_ms": ms, "launches": calls}
+            if short not in doc["kernels"] or doc["kernels"][short]["avg_ms"] * doc["kernels"][short]["launches"] < ms * calls:
+                doc["kernels"][short] = e              # several instantiations: keep the one that carries the time
+    with open(os.path.join(dst_dir, "octree_hbm_traffic.json" if tag != "tmp" else "octree_hbm_traffic_tmp.json"), "w") as g:
+        json.dump(doc, g, indent=1)
 
 
 if __name__ == "__main__":

@@ -101,3 +101,54 @@ def test_reference_consumer_reads_our_checkpoint(tmp_path, monkeypatch):
     np.testing.assert_allclose(sigma.numpy(), o_sigma.numpy(), atol=2e-6)
     np.testing.assert_allclose(rgb_c.numpy(), o_rgb_c.numpy(), atol=2e-6)
     np.testing.assert_allclose(sigma_c.numpy(), o_sigma_c.numpy(), atol=2e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_torch_state_dict_checkpoint_of_the_reference_twin(tmp_path, monkeypatch):
+    """The reference's OTHER input format (octree/nerf/models.py:52-63, taken without --is_jaxnerf_ckpt): `*.ckpt` =
+    {"model": state_dict of its torch NerfModel}.  The file is written by the reference's own module here; our reader must
+    fill the arena so that the oracle reproduces the twin's eval_points_raw, and extraction's loader must pick the format the
+    way the reference's flag does -- and refuse to go on with random weights when there is nothing to read."""
+    monkeypatch.syspath_prepend(REF)
+    from octree.nerf import models as ref_models
+    torch.manual_seed(5)
+    model = ref_models.NerfModel(num_coarse_samples=64, num_fine_samples=128, use_viewdirs=False, sh_deg=3,
+                                 sg_dim=-1, num_rgb_channels=48, num_sigma_channels=1)
+    with torch.no_grad():
+        for p in model.parameters():            # biases are zero-initialised: make every leaf distinguishable
+            p.add_(0.01 * torch.randn_like(p))
+    torch.save({"model": model.state_dict()}, str(tmp_path / "000100.ckpt"))
+    torch.save({"model": {k: torch.zeros_like(v) for k, v in model.state_dict().items()}}, str(tmp_path / "000050.ckpt"))
+    ocfg = O.Cfg(sh_deg=3)
+    st = _State(_lib.make_cfg(sh_deg=3), torch.zeros(2 * 505649))
+    st.m += 1.0
+    path = checkpoints.restore_torch_checkpoint(str(tmp_path), st)
+    assert os.path.basename(path) == "000100.ckpt" and float(st.m.abs().max()) == 0.0        # sorted()[-1]; no stale moments
+    pts = (torch.rand(64, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 1.5
+    with torch.no_grad():
+        rgb, sigma = model.eval_points_raw(pts)
+        rgb_c, sigma_c = model.eval_points_raw(pts, coarse=True)
+    params = O.unflatten_params(st.params, ocfg)
+    o_rgb, o_sigma = O.eval_points_raw(params, pts, ocfg)
+    o_rgb_c, o_sigma_c = O.eval_points_raw(params, pts, ocfg, coarse=True)
+    np.testing.assert_allclose(rgb.numpy(), o_rgb.numpy(), atol=2e-6)
+    np.testing.assert_allclose(sigma.numpy(), o_sigma.numpy(), atol=2e-6)
+    np.testing.assert_allclose(rgb_c.numpy(), o_rgb_c.numpy(), atol=2e-6)
+    np.testing.assert_allclose(sigma_c.numpy(), o_sigma_c.numpy(), atol=2e-6)
+    # extraction's loader: format chosen as the reference's flag does
+    from plenoctree_amd.octree import extraction
+    a = types.SimpleNamespace(train_dir=str(tmp_path), is_jaxnerf_ckpt=False)
+    st2 = _State(_lib.make_cfg(sh_deg=3), torch.zeros(2 * 505649))
+    assert "torch state dict" in extraction.load_nerf_checkpoint(a, st2) and torch.equal(st2.params, st.params)
+    a.is_jaxnerf_ckpt = True
+    with pytest.raises(FileNotFoundError):
+        extraction.load_nerf_checkpoint(a, st2)                       # the flag asks for flax; only *.ckpt here
+    checkpoints.save_checkpoint(str(tmp_path), _State(_lib.make_cfg(sh_deg=3), st.params + 1.0, step=9), 9)
+    assert "flax msgpack" in extraction.load_nerf_checkpoint(a, st2) and torch.equal(st2.params, st.params + 1.0)
+    empty = tmp_path / "empty"; empty.mkdir()
+    a = types.SimpleNamespace(train_dir=str(empty), is_jaxnerf_ckpt=False)
+    with pytest.raises(FileNotFoundError):
+        extraction.load_nerf_checkpoint(a, st2)
+    # a view-conditioned twin is rejected, not half-loaded
+    with pytest.raises(ValueError, match="view-conditioned"):
+        checkpoints.torch_state_dict_to_tree({"MLP_0.bottleneck_layer.weight": torch.zeros(1)})

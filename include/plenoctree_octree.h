@@ -119,10 +119,15 @@ int pxo_octree_set_lanes_per_ray(int forward, int backward);
  * the two weight-mask marchers); process-wide, validated, no environment variables are read anywhere in the library.
  *   PXO_TUNE_GW_MARCHER      -1 chosen on the device by the occupied fraction of the grid (default), 0 per-sample, 1 slab-staged
  *   PXO_TUNE_BWD_CACHE_ROWS  rows of the backward renderer's per-wave write-combining cache: 16 (default), 0 (direct
- *                            scatter), 4, 8, 32, 64 */
+ *                            scatter), 4, 8, 32, 64
+ *   PXO_TUNE_BWD_UPDATE      how a sample's gradient row reaches that cache: 0 the whole wave on one sample's row at a time,
+ *                            1 every ray's own 4 lanes on its row, all 16 rays of the wave at once (LDS float atomics; misses
+ *                            elect one winner per slot).  Same sums in a different order (float32 round-off apart). */
 #define PXO_TUNE_GW_MARCHER 0
 #define PXO_TUNE_BWD_CACHE_ROWS 1
+#define PXO_TUNE_BWD_UPDATE 2
 int pxo_octree_set_tuning(int knob, int value);
+int pxo_octree_get_tuning(int knob, int* value);
 
 /* Forward.  Rays come either from `cam` (cam != NULL: B must be width*height, ray r = pixel
  * (r % width, r / width), out [H,W,3]) or from explicit arrays origins/dirs/viewdirs [B,3] in world

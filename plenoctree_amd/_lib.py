@@ -139,6 +139,7 @@ SIGNATURES = {
                                        F3, F3, P, P, c_size_t, P]),
     "pxo_octree_set_lanes_per_ray": (c_int, [c_int, c_int]),
     "pxo_octree_set_tuning": (c_int, [c_int, c_int]),
+    "pxo_octree_get_tuning": (c_int, [c_int, POINTER(c_int)]),
     "pxo_octree_render_fwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,

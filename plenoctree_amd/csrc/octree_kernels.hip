@@ -984,17 +984,30 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
 // 4g + q from that ray's lanes (shfl) and adds basis_k(ray) * d_channel at the data indices j, j + 16, .. - the same 64-byte rows per
 // instruction as the 16-lane kernel, with the march running at four times its rays per wave.  Rays that have finished stay in
 // the loop (idle) until the whole wave is done, since every lane takes part in every deal.
-template <int KF, int WC>
+// UPD (WC > 0): how a sample's gradient row reaches the wave's cache.
+//   0  one sample at a time, the whole wave on its 3K+1-float row (15 of 64 lanes idle for SH16, ~27 vector instructions per
+//      sample, ~12 samples per march step of the wave's 16 rays: the update phase issued twice the instructions of the march);
+//   1  every ray's own 4 lanes add its sample's row -- 13 (SH16) / 19 (SH25) LDS float atomics per lane, all 16 rays at once --
+//      when the slot already holds the ray's leaf (a hit); rays that miss elect ONE winner per slot through LDS, the winners' old
+//      rows leave as before (one contiguous row of global atomics per row, the whole wave on it) and the winners write their new
+//      rows themselves; rays that lost an election go round again and usually hit the row the winner has just installed (the
+//      neighbouring pixel entered the same leaf in the same step).  A wave's LDS operations execute in program order, so the
+//      hits of a round land before the evictions read the rows and the installs after.  r05c: 4.70 -> see DESIGN 8.2.
+template <int KF, int WC, int UPD = 0>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(RenderArgs A, const float* __restrict__ fwd_rgb,
                                                                              const float* __restrict__ grad_out,
                                                                              float* __restrict__ grad_data) {
   using G = RowGeom<4>;
   constexpr int kRow = 4, kRaysPerBlock = G::kRaysPerBlock;
   constexpr int kDmax = 3 * (KF > 0 ? KF : 25) + 1, kRM = (kDmax + 63) / 64, kWCn = WC > 0 ? WC : 1;
+  constexpr int kPM = (kDmax + kRow - 1) / kRow;                 // row elements per lane of a ray (UPD 1): l, l + 4, ...
   __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
   __shared__ float s_basis[kRaysPerBlock][25];
   __shared__ float s_rows[kRenderThreads / 64][kWCn][WC > 0 ? kDmax : 1];
+  __shared__ int s_tag[kRenderThreads / 64][UPD ? kWCn : 1];     // UPD 1: the leaf whose row sits in slot i (-1: empty)
+  __shared__ int s_own[kRenderThreads / 64][UPD ? kWCn : 1];     //        the ray that won the slot in this round
   static_assert(WC <= 64, "one tag per lane");
+  static_assert(UPD == 0 || WC > 0, "the ray-parallel update needs the cache");
   const int row = threadIdx.x / kRow, l = threadIdx.x % kRow, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tagv = -1;                                 // lane i: the leaf whose row sits in slot i of this wave's cache (-1: empty)
   int64_t ray = 0;
@@ -1071,6 +1084,20 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
     wch[m] = idx < 3 * Kc ? idx / Kc : 3;
     wof[m] = idx < 3 * Kc ? idx - wch[m] * Kc : 0;
   }
+  // ray-parallel side (UPD 1): this lane owns the data indices l, l + 4, .. of its OWN ray's sample row: basis value and channel
+  // (3 = the sigma entry, 4 = past the row) per owned index
+  float pb[UPD ? kPM : 1];
+  int pch[UPD ? kPM : 1];
+  if (UPD) {
+#pragma unroll
+    for (int m = 0; m < kPM; ++m) {
+      const int idx = l + kRow * m;
+      pch[m] = idx < 3 * Kc ? idx / Kc : (idx == D - 1 ? 3 : 4);
+      pb[m] = idx < 3 * Kc ? s_basis[row][idx - pch[m] * Kc] : (idx == D - 1 ? 1.0f : 0.0f);
+    }
+    if (lane < kWCn) s_tag[wave][lane] = -1;
+  }
+  const int ray_in_wave = lane >> 2;
   const float* __restrict__ data = A.tree.data;
   const int32_t* __restrict__ child = A.tree.child;
 
@@ -1159,7 +1186,48 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
         running = tn > t && tn < r.tmax;           // !(tn > t): step below the resolution of t, stop rather than spin
         t = tn;
       }
-      if (pass == 1 && WC > 0) {
+      if (pass == 1 && WC > 0 && UPD == 1) {
+        float vv[kPM];
+#pragma unroll
+        for (int m = 0; m < kPM; ++m)
+          vv[m] = pb[m] * (pch[m] == 0 ? e0 : (pch[m] == 1 ? e1 : (pch[m] == 2 ? e2 : es)));
+        const int slot = (int)(((uint32_t)leaf_i * 2654435761u) >> 16) & (kWCn - 1);
+        float* const rowp = s_rows[wave][slot] + l;
+        bool pend = has;
+        while (__builtin_amdgcn_ballot_w64(pend) != 0) {
+          const int tag = pend ? s_tag[wave][slot] : -2;
+          if (pend && tag == leaf_i) {                          // hit: this ray's 4 lanes add its row
+#pragma unroll
+            for (int m = 0; m < kPM; ++m)
+              if (pch[m] < 4) __hip_atomic_fetch_add(rowp + kRow * m, vv[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pend = false;
+          }
+          if (pend && l == 0) s_own[wave][slot] = ray_in_wave;   // the rays that missed: one winner per slot
+          const bool win = pend && s_own[wave][slot] == ray_in_wave;
+          // the winners' old rows leave, each as ONE contiguous row of atomics with the whole wave on it
+          uint64_t em = __builtin_amdgcn_ballot_w64(win && l == 0 && tag >= 0);
+          while (em) {
+            const int src = __builtin_ctzll(em);
+            em &= em - 1;
+            const int sl = __builtin_amdgcn_readlane(slot, src);
+            const int tg = __builtin_amdgcn_readlane(tag, src);
+            const float* rp = s_rows[wave][sl];
+#pragma unroll
+            for (int m = 0; m < kRM; ++m) {
+              const int idx = lane + 64 * m;
+              if (idx < D) unsafeAtomicAdd(grad_data + (int64_t)tg * D + idx, rp[idx]);
+            }
+          }
+          if (win) {                                            // ... and the winners start their new rows
+#pragma unroll
+            for (int m = 0; m < kPM; ++m)
+              if (pch[m] < 4) rowp[kRow * m] = vv[m];
+            if (l == 0) s_tag[wave][slot] = leaf_i;
+            pend = false;
+          }
+        }
+      }
+      if (pass == 1 && WC > 0 && UPD == 0) {
         // one sample at a time, the whole wave on its row: hit -> add in LDS; miss -> the evicted row leaves as ONE
         // contiguous row of atomics, the new row starts from this sample
         uint64_t hm = __builtin_amdgcn_ballot_w64(has && l == 0);
@@ -1215,7 +1283,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
   }
   if (WC > 0) {                                  // rows still held by the wave
     for (int sl = 0; sl < WC; ++sl) {
-      const int tag = __builtin_amdgcn_readlane(tagv, sl);
+      const int tag = UPD ? __builtin_amdgcn_readfirstlane(s_tag[wave][sl]) : __builtin_amdgcn_readlane(tagv, sl);
       if (tag < 0) continue;
 #pragma unroll
       for (int m = 0; m < kRM; ++m) {
@@ -1600,6 +1668,7 @@ static int render_row(bool backward, int data_dim) {
 // cost occupancy: 35 KB of LDS per workgroup).  pxo_octree_set_tuning(PXO_TUNE_BWD_CACHE_ROWS, 0 | 4 | 8 | 16 | 32 | 64)
 // selects another instantiation for A/B runs (0 = direct scatter); anything else is rejected there.
 static int g_bwd_wc_rows = 16;
+static int g_bwd_update = 0;     // PXO_TUNE_BWD_UPDATE: 0 the whole wave on one sample's row, 1 every ray's 4 lanes on its own row
 static int bwd_wc_slots() { return g_bwd_wc_rows; }
 
 static int render_args(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
@@ -1655,9 +1724,23 @@ int pxo_octree_set_tuning(int knob, int value) {
                   "pxo_octree_set_tuning: write-combining rows must be 0, 4, 8, 16, 32 or 64 (got %d)", value);
       g_bwd_wc_rows = value;
       return PXO_OK;
+    case PXO_TUNE_BWD_UPDATE:
+      PXO_REQUIRE(value == 0 || value == 1, "pxo_octree_set_tuning: backward update must be 0 (wave per sample) or 1 (ray-parallel), got %d", value);
+      g_bwd_update = value;
+      return PXO_OK;
     default:
       set_error("pxo_octree_set_tuning: unknown knob %d", knob);
       return PXO_ERR_ARG;
+  }
+}
+
+int pxo_octree_get_tuning(int knob, int* value) {
+  PXO_REQUIRE(value != nullptr, "pxo_octree_get_tuning: NULL pointer");
+  switch (knob) {
+    case PXO_TUNE_GW_MARCHER: *value = g_gw_marcher; return PXO_OK;
+    case PXO_TUNE_BWD_CACHE_ROWS: *value = g_bwd_wc_rows; return PXO_OK;
+    case PXO_TUNE_BWD_UPDATE: *value = g_bwd_update; return PXO_OK;
+    default: set_error("pxo_octree_get_tuning: unknown knob %d", knob); return PXO_ERR_ARG;
   }
 }
 
@@ -1705,7 +1788,15 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
               (double)opts->stop_thresh);
   switch (row) {
     case 4:
-#define PXO_BWD4W(KF_, WC_) hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_, WC_>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, out_rgb, grad_out, grad_data)
+#define PXO_BWD4W(KF_, WC_)                                                                                                         \
+  do {                                                                                                                            \
+    if (g_bwd_update == 1 && WC_ > 0)                                                                                             \
+      hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_, WC_, (WC_ > 0 ? 1 : 0)>), dim3(grid), dim3(kRenderThreads), 0,             \
+                         (hipStream_t)stream, A, out_rgb, grad_out, grad_data);                                                   \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((octree_render_bwd4_kernel<KF_, WC_, 0>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A,    \
+                         out_rgb, grad_out, grad_data);                                                                          \
+  } while (0)
 #define PXO_BWD4(KF_)                                     \
   switch (bwd_wc_slots()) {                               \
     case 4: PXO_BWD4W(KF_, 4); break;                     \

@@ -152,7 +152,13 @@ def set_lanes_per_ray(forward=0, backward=0):
     check(_lib.load().pxo_octree_set_lanes_per_ray(int(forward), int(backward)), "pxo_octree_set_lanes_per_ray")
 
 
-TUNE_GW_MARCHER, TUNE_BWD_CACHE_ROWS = 0, 1
+TUNE_GW_MARCHER, TUNE_BWD_CACHE_ROWS, TUNE_BWD_UPDATE = 0, 1, 2
+
+
+def get_tuning(knob):
+    v = ctypes.c_int(0)
+    check(_lib.load().pxo_octree_get_tuning(int(knob), ctypes.byref(v)), "pxo_octree_get_tuning")
+    return v.value
 
 
 def set_tuning(knob, value):

@@ -86,13 +86,23 @@ def main():
     p.add_argument("--hard", action="store_true", help="exact zeros outside the spheres (as a trained, relu'd density has) instead of fuzzy tails")
     p.add_argument("--no-roofline", action="store_true", help="skip the counting passes")
     p.add_argument("--reps", type=int, default=2)
+    p.add_argument("--tune", default="", help="A/B only: pxo_octree_set_tuning knobs, e.g. bwd_update=1,bwd_cache_rows=32,gw_marcher=0")
     a = p.parse_args()
-    print(json.dumps(measure(a)), flush=True)
+    if a.tune:
+        from plenoctree_amd import octree_ops as oops
+        knobs = {"gw_marcher": oops.TUNE_GW_MARCHER, "bwd_cache_rows": oops.TUNE_BWD_CACHE_ROWS, "bwd_update": oops.TUNE_BWD_UPDATE}
+        for kv in a.tune.split(","):
+            k, _, v = kv.partition("=")
+            oops.set_tuning(knobs[k], int(v))
+    out = measure(a)
+    if a.tune:
+        out["tuning"] = a.tune
+    print(json.dumps(out), flush=True)
 
 
 def defaults(**over):
     """The argument namespace of `measure` for callers that are not this CLI (bench.py's `octree` record)."""
-    a = argparse.Namespace(depth=8, size=800, step=1e-4, cams=8, basis=16, gw_only=False, hard=False, no_roofline=False, reps=2)
+    a = argparse.Namespace(depth=8, size=800, step=1e-4, cams=8, basis=16, gw_only=False, hard=False, no_roofline=False, reps=2, tune="")
     for k, v in over.items():
         setattr(a, k, v)
     return a

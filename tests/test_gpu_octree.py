@@ -272,8 +272,18 @@ def test_work_counters_match_the_oracle_march():
         (got, rays, samples, occ, int(seen.sum()))
 
 
+@pytest.fixture(params=[0, 1], ids=["wave_per_sample", "ray_parallel"])
+def bwd_update(request):
+    """Both forms of the backward renderer's cache update (PXO_TUNE_BWD_UPDATE), each held to the oracle."""
+    oops = _oops()
+    default = oops.get_tuning(oops.TUNE_BWD_UPDATE)
+    oops.set_tuning(oops.TUNE_BWD_UPDATE, request.param)
+    yield request.param
+    oops.set_tuning(oops.TUNE_BWD_UPDATE, default)
+
+
 @pytest.mark.parametrize("K", [4, 16, 25])
-def test_octree_render_gradient_matches_oracle(K):
+def test_octree_render_gradient_matches_oracle(K, bwd_update):
     oops = _oops(); dev = _gpu()
     t = _random_tree(2, 30 + K, K, p=0.3)
     view, (child, data) = _device_tree(t, dev)
@@ -649,8 +659,23 @@ def test_render_kernel_variants_agree_at_image_size(K):
         g2 = torch.zeros_like(data)
         oops.set_lanes_per_ray(4, 4)
         oops.octree_render_persp_bwd(view, c2w, W, H, fx, opt, gout, g2)          # two marches, no forward image
+        # the 4-lane backward's cache: both update forms, every cache size
+        default_upd, default_rows = oops.get_tuning(oops.TUNE_BWD_UPDATE), oops.get_tuning(oops.TUNE_BWD_CACHE_ROWS)
+        try:
+            for upd in (0, 1):
+                for rows in (4, 16, 64):
+                    oops.set_tuning(oops.TUNE_BWD_UPDATE, upd); oops.set_tuning(oops.TUNE_BWD_CACHE_ROWS, rows)
+                    g = torch.zeros_like(data)
+                    oops.octree_render_persp_bwd(view, c2w, W, H, fx, opt, gout, g, out_rgb=imgs[4])
+                    grads[("cache", upd, rows)] = g
+        finally:
+            oops.set_tuning(oops.TUNE_BWD_UPDATE, default_upd); oops.set_tuning(oops.TUNE_BWD_CACHE_ROWS, default_rows)
     finally:
         oops.set_lanes_per_ray(0, 0)
+    for key, g in grads.items():
+        if isinstance(key, tuple):
+            rel = float((g.double() - grads[16].double()).norm() / grads[16].double().norm())
+            assert rel < 1e-5, (key, rel)
     assert float(imgs[16].std()) > 0.05                                              # a real image, not background
     for lanes in (4, 8):
         close(f"SH{K} image {lanes} vs 16 lanes", imgs[lanes], imgs[16], rtol=0, atol=2e-5)

@@ -154,7 +154,8 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
  *   counts[3] child-pointer loads of the leaf lookups (tree marcher only)
  * counts: 4 device uint64, ACCUMULATED (zero them first).  leaf_seen [n_internal*8] / voxel_seen [reso^3] (uint8, may be
  * NULL): set to 1 where a sample above the threshold fell, so that the distinct rows a launch must fetch from HBM at
- * least once can be counted. */
+ * least once can be counted.  pxo_grid_weight_count_work takes power-of-two grids only (reso >= 4: every grid the extraction
+ * makes): it repeats the march of the power-of-two weight-mask kernels, whose division by reso is an exact multiplication. */
 int pxo_octree_count_work(const PxoTree* tree, const PxoCamera* cam, const PxoRenderOpts* opts,
                           unsigned long long* counts, uint8_t* leaf_seen, void* stream);
 int pxo_grid_weight_count_work(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,

@@ -1840,6 +1840,10 @@ int pxo_grid_weight_count_work(const float* sigma_grid, int reso, const float* c
   if (int rc = check_opts(opts, "pxo_grid_weight_count_work")) return rc;
   PXO_REQUIRE(sigma_grid && c2w_all && offset && invradius && counts && reso >= 1 && n_cams >= 1 && width >= 1 && height >= 1,
               "pxo_grid_weight_count_work: bad arguments");
+  // the counting march divides by the grid size as the power-of-two weight-mask kernels do (an exact multiplication); for
+  // other sizes the renderer's own step arithmetic differs in the last bit and the counted sample sequence could too
+  PXO_REQUIRE((reso & (reso - 1)) == 0 && reso >= 4, "pxo_grid_weight_count_work: reso %d is not a power of two >= 4 "
+              "(the counters repeat the march of the power-of-two weight-mask kernels only)", reso);
   Vec3 o, ir;
   for (int a = 0; a < 3; ++a) { o.v[a] = offset[a]; ir.v[a] = invradius[a]; }
   const int64_t rays = (int64_t)width * height * n_cams;

@@ -490,6 +490,12 @@ def test_octree_error_paths():
     img = oops.octree_render_persp(view, c2w, 4, 4, 5.0, fast)
     with pytest.raises(PxoError, match="stop_thresh"):
         oops.octree_render_persp_bwd(view, c2w, 4, 4, 5.0, fast, torch.ones_like(img), torch.zeros_like(keep[1]), out_rgb=img)
+    # the weight-mask work counters repeat the power-of-two kernels' march only
+    with pytest.raises(PxoError, match="power of two"):
+        oops.grid_weight_count_work(torch.zeros(12 ** 3, device=dev), 12, c2w[None], 5.0, 5.0, 4, 4,
+                                    oops.render_opts(1e-3), t.offset, t.invradius)
+    with pytest.raises(PxoError, match="pxo_octree_set_tuning"):
+        oops.set_tuning(oops.TUNE_BWD_UPDATE, 2)
 
 
 def _write_checkpoint(tmp_path, args, flat):

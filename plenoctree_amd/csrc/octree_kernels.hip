@@ -342,20 +342,25 @@ __device__ __forceinline__ float clamp_coord(float x) { return fminf(fmaxf(x, 0.
 // invdir >= 0, t1 otherwise - i.e. t1 + add with the per-ray addend add = invdir >= 0 ? invdir : 0 (t1 + 0 is t1).  Same
 // operations, same roundings as dda_unit (this file is compiled without contraction), 9 instructions instead of 19.
 // Returns tmax (= tmax - tmin).
+// init(invdir, s) with s a POWER OF TWO returns s x the exit distance instead: scaling by 2^k commutes with every rounding of
+// the mul / add / min chain (no operand gets near the under- or overflow range), so `cell_exit(local) * 2^-k` of the
+// power-of-two weight-mask marchers is folded into the per-ray constants -- bit for bit the same step length, one
+// multiplication per sample less.
 struct CellExit {
-  float inv[3], add[3];
-  __device__ __forceinline__ void init(const float (&invdir)[3]) {
+  float inv[3], add[3], cap;
+  __device__ __forceinline__ void init(const float (&invdir)[3], float pow2_scale = 1.0f) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      inv[a] = invdir[a];
-      add[a] = invdir[a] >= 0.0f ? invdir[a] : 0.0f;
+      inv[a] = invdir[a] * pow2_scale;
+      add[a] = invdir[a] >= 0.0f ? invdir[a] * pow2_scale : 0.0f;
     }
+    cap = 1e9f * pow2_scale;
   }
   __device__ __forceinline__ float operator()(const float (&cen)[3]) const {
     const float e0 = -cen[0] * inv[0] + add[0];
     const float e1 = -cen[1] * inv[1] + add[1];
     const float e2 = -cen[2] * inv[2] + add[2];
-    return fminf(fminf(1e9f, e0), fminf(e1, e2));
+    return fminf(fminf(cap, e0), fminf(e1, e2));
   }
 };
 // 2^-(depth+1) exactly: dividing the cell-local distance by the cell count per axis (a power of two) is this multiplication
@@ -420,10 +425,24 @@ struct GwSelect {
 
 // POW2: reso is a power of two (every grid the extraction makes): the division by it is an exact multiplication and
 // the brick index is assembled from bit fields in 32 bits (reso <= 1024).
+constexpr int kGwLutMax = 512;        // entries per axis of the per-sample marcher's index tables (larger grids: arithmetic)
 template <bool BRICK, bool POW2>
 __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma, int reso, const float* __restrict__ c2w_all,
                                                  int n_cams, float fx, float fy, int W, int H, const PxoRenderOpts& opt,
-                                                 const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits) {
+                                                 const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits,
+                                                 uint32_t* __restrict__ s_lut = nullptr) {
+  // BRICK && POW2: the bricked index of a voxel is the OR of three per-axis bit patterns; they come from three small LDS
+  // tables (s_lut: 3 x kGwLutMax words of workgroup scratch) instead of 13 shift / mask / or instructions per sample.  Filled
+  // by the whole workgroup before any thread leaves.
+  const bool lut = BRICK && POW2 && s_lut != nullptr && reso <= kGwLutMax;       // workgroup-uniform
+  if (lut) {
+    const int lbq = 31 - __clz(reso >> 2), lr = lbq + 2;               // reso = 2^lr
+    for (int e = threadIdx.x; e < 3 * reso; e += blockDim.x) {
+      const int a = e >> lr, x = e & (reso - 1);
+      s_lut[a * kGwLutMax + x] = ((uint32_t)(x >> 2) << ((2 - a) * lbq + 6)) | ((uint32_t)(x & 3) << ((2 - a) * 2));
+    }
+    __syncthreads();
+  }
   // 8x8 pixel tiles per 64-thread wave keep the rays of a wave in neighbouring voxels
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int64_t b = blockIdx.x;
@@ -442,23 +461,31 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
   const float inv_cube = 1.0f / cube;            // exact when POW2
   const int lb = 31 - __clz(reso >> 2);          // POW2: log2 of bricks per axis
   CellExit cell_exit;
-  cell_exit.init(r.invdir);
+  cell_exit.init(r.invdir, POW2 ? inv_cube : 1.0f);
+  // POW2: the grid size is a power of two, so (o + t d) * cube == o * cube + t * (d * cube) and the clamp scales with it, bit
+  // for bit (scaling by 2^k commutes with the roundings of the separate mul and add this file is compiled to): the three
+  // multiplications by cube leave the loop.  r05: 47 -> 35 vector instructions per sample together with the index tables below.
+  const float sc = POW2 ? cube : 1.0f;
+  const float so[3] = {r.o[0] * sc, r.o[1] * sc, r.o[2] * sc}, sd[3] = {r.d[0] * sc, r.d[1] * sc, r.d[2] * sc};
+  const float chi = (1.0f - 1e-6f) * sc;
   float t = r.tmin, light = 1.0f;
   while (t < r.tmax) {
     float local[3];
     int c[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float p = clamp_coord(r.o[a] + t * r.d[a]) * cube;
+      // (v_med3_f32: what the compiler makes of clamp_coord's constant bounds; spelled out because `chi` is a register here)
+      const float p = POW2 ? __builtin_amdgcn_fmed3f(so[a] + t * sd[a], 0.0f, chi) : clamp_coord(r.o[a] + t * r.d[a]) * cube;
       c[a] = (int)p;                             // p >= 0: truncation == floor
       local[a] = __builtin_amdgcn_fractf(p);     // p - floor(p)
     }
     const float s1 = cell_exit(local);
-    const float delta_t = (POW2 ? s1 * inv_cube : s1 / cube) + opt.step_size;
+    const float delta_t = (POW2 ? s1 : s1 / cube) + opt.step_size;
     int64_t idx;
     if (BRICK && POW2) {
       const uint32_t x = (uint32_t)c[0], y = (uint32_t)c[1], z = (uint32_t)c[2];
-      idx = (uint32_t)(((x >> 2) << (2 * lb + 6)) | ((y >> 2) << (lb + 6)) | ((z >> 2) << 6) | ((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
+      if (lut) idx = (uint32_t)(s_lut[x] | s_lut[kGwLutMax + y] | s_lut[2 * kGwLutMax + z]);
+      else idx = (uint32_t)(((x >> 2) << (2 * lb + 6)) | ((y >> 2) << (lb + 6)) | ((z >> 2) << 6) | ((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
     } else {
       idx = BRICK ? brick_index(c[0], c[1], c[2], reso >> 2) : ((int64_t)c[0] * reso + c[1]) * reso + c[2];
     }
@@ -488,9 +515,8 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
 template <int kWin>
 __device__ __forceinline__ void grid_weight_slab_body(const float* __restrict__ sigma, int reso, const float* __restrict__ c2w_all,
                                                       int n_cams, float fx, float fy, int W, int H, const PxoRenderOpts& opt,
-                                                      const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits) {
-  __shared__ float s_sigma[kWin * kWin * 64];
-  __shared__ int s_w[kWin * kWin * 64];
+                                                      const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits,
+                                                      float* __restrict__ s_sigma, int* __restrict__ s_w) {
   __shared__ int s_first;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int64_t b = blockIdx.x;
@@ -538,21 +564,24 @@ __device__ __forceinline__ void grid_weight_slab_body(const float* __restrict__ 
       pd[i] = perm[i] == 0 ? r.d[0] : (perm[i] == 1 ? r.d[1] : r.d[2]);
       pinv[i] = perm[i] == 0 ? r.invdir[0] : (perm[i] == 1 ? r.invdir[1] : r.invdir[2]);
     }
-    cell_exit.init(pinv);
+    cell_exit.init(pinv, inv_cube);           // the exit distance already divided by the grid size (exact: a power of two)
     delta_scale = r.delta_scale;
     tmax = r.tmax;
     t = r.tmin;
   }
+  // the ray in grid units: (o + t d) * cube == o cube + t (d cube), bit for bit, for a power-of-two cube (see grid_weight_body)
+  const float so0 = po[0] * cube, so1 = po[1] * cube, so2 = po[2] * cube, sd0 = pd[0] * cube, sd1 = pd[1] * cube, sd2 = pd[2] * cube;
+  const float chi = (1.0f - 1e-6f) * cube;
   // the pending sample: cell (permuted axes) and step length at the current t
   int c0 = 0, c1 = 0, c2 = 0;
   float delta_t = 0.0f;
   auto next_sample = [&]() {
     float local[3];
-    const float p0 = clamp_coord(po[0] + t * pd[0]) * cube, p1 = clamp_coord(po[1] + t * pd[1]) * cube,
-                p2 = clamp_coord(po[2] + t * pd[2]) * cube;
+    const float p0 = __builtin_amdgcn_fmed3f(so0 + t * sd0, 0.0f, chi), p1 = __builtin_amdgcn_fmed3f(so1 + t * sd1, 0.0f, chi),
+                p2 = __builtin_amdgcn_fmed3f(so2 + t * sd2, 0.0f, chi);
     c0 = (int)p0; c1 = (int)p1; c2 = (int)p2;
     local[0] = __builtin_amdgcn_fractf(p0); local[1] = __builtin_amdgcn_fractf(p1); local[2] = __builtin_amdgcn_fractf(p2);
-    delta_t = cell_exit(local) * inv_cube + opt.step_size;
+    delta_t = cell_exit(local) + opt.step_size;
   };
   if (alive) next_sample();
   __syncthreads();
@@ -649,8 +678,15 @@ __global__ __launch_bounds__(256) void grid_weight_pow2_kernel(const float* __re
                                                                 const float* __restrict__ c2w_all, int n_cams, float fx, float fy,
                                                                 int W, int H, PxoRenderOpts opt, Vec3 offset, Vec3 invradius,
                                                                 int* __restrict__ weight_bits, GwSelect sel) {
-  if (sel.dense()) grid_weight_slab_body<6>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits);
-  else grid_weight_body<true, true>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits);
+  // one block of workgroup scratch for either marcher: the slab marcher's sigma / weight windows, or the per-sample marcher's
+  // index tables (3 x 512 words fit the sigma window)
+  constexpr int kWin = 6;
+  __shared__ __attribute__((aligned(16))) float s_sigma[kWin * kWin * 64];
+  __shared__ int s_w[kWin * kWin * 64];
+  static_assert(kWin * kWin * 64 >= 3 * kGwLutMax, "the index tables live in the sigma window");
+  if (sel.dense()) grid_weight_slab_body<kWin>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits, s_sigma, s_w);
+  else grid_weight_body<true, true>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits,
+                                    reinterpret_cast<uint32_t*>(s_sigma));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ inverse-CDF sampling.
 Bounds, fixed numbers:
   Stats      against the float64 oracle: rtol 2e-5, or within STATS_FACTOR x the distance of the oracle's own float32
              evaluation from its float64 one (with random u the fine samples of a float32 and a float64 evaluation differ in
-             the bins next to empty stretches of the cdf: the fine loss of this batch moves by 4e-5 relative either way);
+             the bins next to empty stretches of the cdf: the fine loss of this batch moves by 3e-5 (oracle float32) / 3.8e-5 (HIP) relative, r05d);
              loss_sp 5e-3 (1 - mean(exp(-0.05 relu(sigma))) of a mostly empty volume is a difference of nearly equal numbers
              in float32; same bar as L1 in tests/test_gpu_reference_fixtures.py)
   gradient   relative L2 error per MLP against the float64 oracle <= GRAD_FACTOR x the distance of the oracle's OWN float32
@@ -127,7 +127,7 @@ def test_trained_step_matches_f64_oracle(trained):
     print("trained step:", json.dumps(rec))
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
         rtol = 5e-3 if k == "loss_sp" else 2e-5
-        tol = max(rtol * abs(st64[k]), STATS_FACTOR * abs(st32[k] - st64[k]), 1e-7)
+        tol = max(rtol * abs(st64[k]), STATS_FACTOR * abs(st32[k] - st64[k]))
         assert abs(float(s0[i]) - st64[k]) <= tol, (k, float(s0[i]), st64[k], st32[k], tol)
     for mi, e_hip, e_cpu in errs:
         bound = min(max(GRAD_FACTOR * e_cpu, 1e-3), GRAD_CAP)

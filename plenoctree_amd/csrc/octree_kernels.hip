@@ -468,20 +468,22 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
   const float sc = POW2 ? cube : 1.0f;
   const float so[3] = {r.o[0] * sc, r.o[1] * sc, r.o[2] * sc}, sd[3] = {r.d[0] * sc, r.d[1] * sc, r.d[2] * sc};
   const float chi = (1.0f - 1e-6f) * sc;
-  float t = r.tmin, light = 1.0f;
-  while (t < r.tmax) {
+  // One sample: the voxel at parameter `tt` and the step to the next sample.  Neither depends on sigma, so the march is
+  // SOFTWARE-PIPELINED: the next sample's voxel is located and its sigma load issued before the current sample's sigma is
+  // consumed (two loads in flight per ray; the loop was one dependent L2 / HBM round trip per sample).  Same samples, same
+  // arithmetic; a ray that stops on `light <= stop_thresh` has read one sigma it did not need.
+  auto locate = [&](float tt, int64_t& idx, float& delta_t) {
     float local[3];
     int c[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       // (v_med3_f32: what the compiler makes of clamp_coord's constant bounds; spelled out because `chi` is a register here)
-      const float p = POW2 ? __builtin_amdgcn_fmed3f(so[a] + t * sd[a], 0.0f, chi) : clamp_coord(r.o[a] + t * r.d[a]) * cube;
+      const float p = POW2 ? __builtin_amdgcn_fmed3f(so[a] + tt * sd[a], 0.0f, chi) : clamp_coord(r.o[a] + tt * r.d[a]) * cube;
       c[a] = (int)p;                             // p >= 0: truncation == floor
       local[a] = __builtin_amdgcn_fractf(p);     // p - floor(p)
     }
     const float s1 = cell_exit(local);
-    const float delta_t = (POW2 ? s1 : s1 / cube) + opt.step_size;
-    int64_t idx;
+    delta_t = (POW2 ? s1 : s1 / cube) + opt.step_size;
     if (BRICK && POW2) {
       const uint32_t x = (uint32_t)c[0], y = (uint32_t)c[1], z = (uint32_t)c[2];
       if (lut) idx = (uint32_t)(s_lut[x] | s_lut[kGwLutMax + y] | s_lut[2 * kGwLutMax + z]);
@@ -489,7 +491,24 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
     } else {
       idx = BRICK ? brick_index(c[0], c[1], c[2], reso >> 2) : ((int64_t)c[0] * reso + c[1]) * reso + c[2];
     }
-    const float sg = sigma[idx];
+  };
+  float t = r.tmin, light = 1.0f;
+  if (!(t < r.tmax)) return;
+  int64_t idx;
+  float delta_t;
+  locate(t, idx, delta_t);
+  float sg = sigma[idx];
+  for (;;) {
+    // the sample after this one (if the march goes on): located and requested now
+    const float tn = t + delta_t;
+    const bool more = tn > t && tn < r.tmax;     // !(tn > t): step below the resolution of t, stop rather than spin
+    // (unconditionally: the position is clamped into the grid, so the address is valid even past tmax, and a straight-line
+    // body is what lets the compiler wait for the OLDER of the two loads only -- with the request inside `if (more)` it
+    // waited for both at the join and nothing overlapped)
+    int64_t idx_n;
+    float delta_n;
+    locate(tn, idx_n, delta_n);
+    const float sg_n = sigma[idx_n];
     if (sg > opt.sigma_thresh) {
       const float att = expf(-(delta_t * r.delta_scale) * sg);
       const float w = light * (1.0f - att);
@@ -498,9 +517,8 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
       if (wb > weight_bits[idx]) atomicMax(weight_bits + idx, wb);     // w >= 0: integer order == float order
       if (light <= opt.stop_thresh) return;
     }
-    const float tn = t + delta_t;
-    if (!(tn > t)) return;                     // step below the resolution of t: stop rather than spin
-    t = tn;
+    if (!more) return;
+    t = tn; idx = idx_n; delta_t = delta_n; sg = sg_n;
   }
 }
 

@@ -914,21 +914,37 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
     float t = r.tmin, light = 1.0f;
     float out[3] = {0.f, 0.f, 0.f};
     bool stopped = false;
-    while (t < r.tmax) {
+    // One sample = the leaf at parameter tt and the step to the next sample; neither depends on the leaf's DATA.  The march is
+    // software-pipelined on that: a sample's sigma is requested, then the NEXT sample is located (its child-pointer loads
+    // travel together with the sigma request), and only then is the current sample shaded -- per sample one dependent L2 round
+    // trip less (lookup || sigma -> coefficients instead of lookup -> sigma -> coefficients).  Same samples, same arithmetic.
+    auto locate = [&](float tt, int64_t& leaf_o, float& delta_o) {
       float pos[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + t * r.d[a]);
+      for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + tt * r.d[a]);
       int depth;
-      const int64_t leaf = mk.find(child, pos, depth);
+      leaf_o = mk.find(child, pos, depth);
       const float cube = (float)(2u << depth);
       float local[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) local[a] = __builtin_amdgcn_fractf(pos[a] * cube);
-      const float delta_t = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
+      delta_o = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
+    };
+    int64_t leaf = 0;
+    float delta_t = 0.0f;
+    bool more = t < r.tmax;
+    if (more) locate(t, leaf, delta_t);
+    while (more) {
       const float* __restrict__ val = data + leaf * D;
       const float sg = val[D - 1];
+      const float tn = t + delta_t;
+      more = tn > t && tn < r.tmax;              // !(tn > t): step below the resolution of t, stop rather than spin
+      const int64_t leaf_cur = leaf;
+      const float delta_cur = delta_t;
+      if (more) locate(tn, leaf, delta_t);       // the next sample, while sigma is on its way
+      t = tn;
       if (sg > A.opt.sigma_thresh) {
-        const float dtw = delta_t * r.delta_scale;
+        const float dtw = delta_cur * r.delta_scale;
         const float att = expf(-dtw * sg);
         const float weight = light * (1.0f - att);
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -1001,7 +1017,7 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
           const float d0 = weight * g[0] * c0 * (1.0f - c0);
           const float d1 = weight * g[1] * c1 * (1.0f - c1);
           const float d2 = weight * g[2] * c2 * (1.0f - c2);
-          float* __restrict__ gv = grad_data + leaf * D;
+          float* __restrict__ gv = grad_data + leaf_cur * D;
 #pragma unroll
           for (int j = 0; j < kMaxLoads; ++j) {
             if (j < nload) {
@@ -1014,9 +1030,6 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
           if (l == 0) unsafeAtomicAdd(gv + D - 1, dtw * (total * light - accum));
         }
       }
-      const float tn = t + delta_t;
-      if (!(tn > t)) break;                    // step below the resolution of t: stop rather than spin
-      t = tn;
     }
     if (pass == 0) {
       if (MODE == 0) {

@@ -113,7 +113,7 @@ def measure(a):
     from plenoctree_amd.nerf_sh.nerf.datasets import pose_spherical
     from plenoctree_amd.octree.svox import N3Tree, VolumeRenderer
     build.build(verbose=False)
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", torch.cuda.current_device())      # the caller's device (bench.py: one rank per GPU)
     depth, reso = a.depth, 2 ** (a.depth + 1)
     K = a.basis
     tree = N3Tree(N=2, data_dim=3 * K + 1, depth_limit=depth, radius=1.5, center=[0, 0, 0], data_format=f"SH{K}", map_location=dev)

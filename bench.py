@@ -215,7 +215,7 @@ def hbm_traffic(kernel):
         k = doc["kernels"][kernel]
         return (k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
                 "profiles/hbm_traffic.json (" + doc.get("source", "rocprofv3 --pmc passes of this command, committed") +
-                "); not measured inside this run")
+                (", code at commit " + doc["commit"] if doc.get("commit") else "") + "); not measured inside this run")
     except Exception:
         return None, None
 

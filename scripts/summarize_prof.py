@@ -97,6 +97,12 @@ def main(src, dst_dir, tag):
         ent["hbm_write_bytes_per_launch"] = int(ent["hbm_write_bytes_per_launch"] / n)
     if traffic["kernels"]:
         import json
+        import subprocess
+        try:                     # which code the counters were collected on (the session ran the working tree of this commit)
+            traffic["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
+                                                        cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
+        except Exception:
+            pass
         with open(os.path.join(dst_dir, "hbm_traffic.json"), "w") as g:
             json.dump(traffic, g, indent=1)
 

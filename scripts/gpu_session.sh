@@ -12,6 +12,8 @@
 #   oprof      rocprofv3 stats + FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py   -> gpurun_out/oprof, opmc{1,2}
 #   pipeline   train -> eval -> extraction -> optimization -> evaluation through the drop-in CLIs -> gpurun_out/converge.log
 #   power      clocks / power sampled while a long bench runs                               -> gpurun_out/smi.log
+#   probe      scripts/contention_probe.py: a stand-in for a collective's kernel beside the step  -> gpurun_out/contention_probe.jsonl
+#   tune       scripts/tune_ab.py $TUNE_ARGS: in-process A/B of pxo_set_tuning variants            -> gpurun_out/tune_ab.jsonl
 #
 #   gpurun --timeout 1500 -- 'STAGES="tests bench prof" bash scripts/gpu_session.sh'
 set -u
@@ -51,11 +53,11 @@ for stage in ${STAGES:-tests bench}; do
   echo "=== stage $stage"
   case $stage in
   tests)
-    rm -f gpurun_out/fullsize_parity.jsonl
+    rm -f gpurun_out/fullsize_parity.jsonl gpurun_out/trained_state_parity.jsonl
     timeout ${TEST_TIMEOUT:-1800} python -m pytest tests -m gpu --durations=15 -q --tb=short -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
     echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
     tail -${TEST_TAIL:-40} gpurun_out/pytest_gpu.log
-    cat gpurun_out/fullsize_parity.jsonl gpurun_out/trained_psnr.json gpurun_out/trained_psnr_twin512.json 2>/dev/null
+    cat gpurun_out/fullsize_parity.jsonl gpurun_out/trained_psnr.json gpurun_out/trained_psnr_twin512.json gpurun_out/trained_state_parity.jsonl 2>/dev/null
     timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
     tail -3 gpurun_out/smoke.log ;;
   bench)
@@ -134,6 +136,12 @@ for stage in ${STAGES:-tests bench}; do
     ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Power|mclk|Temperature \(Sensor (edge|junction)" | tr '\n' ' ' ; echo; sleep 0.5; done ) > gpurun_out/smi.log &
     timeout 120 python bench.py --steps 400 --warmup 3 $HEAD_ARGS > gpurun_out/bench_long.json 2> gpurun_out/bench_long.err
     wait; brief gpurun_out/bench_long.json power; sed -n '1p;8p;16p;24p;32p' gpurun_out/smi.log | cut -c1-400 ;;
+  probe)
+    timeout 300 python scripts/contention_probe.py > gpurun_out/contention_probe.jsonl 2> gpurun_out/contention_probe.err
+    echo "probe exit $?"; cut -c1-170 gpurun_out/contention_probe.jsonl ;;
+  tune)
+    timeout 400 python scripts/tune_ab.py ${TUNE_ARGS:---batches 512,4096 static:tile_sched=0 counter:tile_sched=1} > gpurun_out/tune_ab.jsonl 2> gpurun_out/tune_ab.err
+    echo "tune exit $?"; cut -c1-200 gpurun_out/tune_ab.jsonl ;;
   *) echo "unknown stage $stage" ;;
   esac
 done

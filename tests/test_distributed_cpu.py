@@ -192,3 +192,51 @@ def test_slab_range_partitions_grid():
             assert a[1] == b[0]
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _per_host_worker(rank, world, port, outdir):
+    """`--per_host_image` on gloo ranks: the rank's dataset is a shard of host 0's draw; the shards, gathered in rank order
+    with the collective render_image / the reducer use, must be the single-process batch."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _cpu_feeder import feeder_for
+    from plenoctree_amd import dist
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    datasets.Dataset.feeder_factory = staticmethod(feeder_for)
+    comm = dist.init_from_env(backend="gloo")
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x", "--per_host_image", "true"])
+    utils.update_flags(args); args.factor = 16
+    assert args.per_host_image is True
+    per = 64 // world
+    ds = datasets.get_dataset("train", args, torch.device("cpu"), batch_size=per, seed=20201473, shard=(comm.rank, comm.world))
+    out = []
+    for _ in range(3):
+        b = next(ds)
+        out.append({"pixels": comm.all_gather_cat(b["pixels"]), "rays": [comm.all_gather_cat(r) for r in b["rays"]]})
+    if rank == 0:
+        torch.save(out, os.path.join(outdir, "gathered.pt"))
+    comm.barrier()
+    comm.shutdown()
+
+
+@pytest.mark.timeout(300)
+def test_per_host_image_over_gloo_ranks_replays_the_single_process_batches():
+    """The reference on one host with N devices draws ONE image and ONE set of batch_size pixel ids per step and shards them
+    (nerf_sh/nerf/datasets.py:159-166, nerf_sh/nerf/utils.py:518-522): 4 gloo ranks x 16 rays, gathered in rank order, are the
+    64-ray batches of a single process, step after step."""
+    world = 4
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_per_host_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
+        got = torch.load(os.path.join(outdir, "gathered.pt"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
+    utils.update_flags(args); args.factor = 16
+    whole = datasets.get_dataset("train", args, torch.device("cpu"), batch_size=64, seed=20201473)
+    for g in got:
+        want = next(whole)
+        assert torch.equal(g["pixels"], want["pixels"])
+        for k in range(3):
+            assert torch.equal(g["rays"][k], want["rays"][k])

@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 ARGS = ["--backend", "gloo", "--batch", "8", "--steps", "2", "--warmup", "1", "--strong-rays", "4", "--grid-reso", "8",
         "--eval-step", "2", "--converge-steps", "2", "--converge-views", "1", "--image-factor", "100",
-        "--sparsity-npoints", "16", "--cpu-rays", "8", "--cpu-steps", "1",
+        "--sparsity-npoints", "16", "--cpu-rays", "8", "--cpu-steps", "1", "--cpu-warmup", "1", "--per-host-image",
         "--extras", "converge,strong512,render_fwd,grid512,coarse64,tt_sh25"]
 
 
@@ -78,6 +78,9 @@ def test_bench_two_rank_dry_run():
     s = out["strong512"]
     assert s["rays_per_gpu"] == 4 and s["collectives_per_step"] == 2 and "rccl_init_error" not in s
     assert "cpu_baseline" in out and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    cb = out["cpu_baseline"]          # BASELINE.md section 3's record: both configs[0] shapes, the host, the threads used
+    assert [sh["samples"] for sh in cb["shapes"]] == ["64", "64+128"] and cb["value"] == cb["shapes"][1]["rays_per_s"]
+    assert cb["nproc"] >= cb["cores"] >= 1 and cb["torch_version"] and cb["shapes_dropped"]
     c = out["converge"]
     assert out["eval_psnr"] == c["eval_psnr"] and 0.0 < c["eval_psnr"] < 60.0 and c["views"] == 1
     assert c["rays_per_step"] == 16 and c["view_size"] == [8, 8]

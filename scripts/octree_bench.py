@@ -53,7 +53,8 @@ def hbm_traffic(kernel):
         with open(os.path.join(ROOT, "profiles", "octree_hbm_traffic.json")) as f:
             doc = json.load(f)
         k = doc["kernels"][kernel]
-        return {"read_bytes": k["hbm_read_bytes_per_launch"], "write_bytes": k["hbm_write_bytes_per_launch"],
+        per = float(k.get("cameras_per_launch", 1))          # the weight mask's launch serves several cameras; its roofline is per camera
+        return {"read_bytes": k["hbm_read_bytes_per_launch"] / per, "write_bytes": k["hbm_write_bytes_per_launch"] / per,
                 "source": "profiles/octree_hbm_traffic.json (" + doc.get("source", "rocprofv3 --pmc passes") + "); not measured inside this run"}
     except Exception:
         return None

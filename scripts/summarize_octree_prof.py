@@ -25,7 +25,7 @@ def pmc(path, counter):
     return {k: tot[k] / n[k] for k in tot}, {k: dur[k] / n[k] for k in dur}
 
 
-def main(src, dst_dir, tag):
+def main(src, dst_dir, tag, pmc_cams=2):
     stats = {}
     ks = os.path.join(src, "oprof", "obench_kernel_stats.csv")
     with open(ks) as f:
@@ -59,6 +59,8 @@ def main(src, dst_dir, tag):
         if k in rd and k in wr:
             short = k.split("pxo::")[-1].split("<")[0]
             e = {"hbm_read_bytes_per_launch": rd[k] * 2 * 1024, "hbm_write_bytes_per_launch": wr[k] * 1024, "avg_ms": ms, "launches": calls}
+            if short == "grid_weight_pow2_kernel":       # one launch serves every camera of the call: the PMC passes ran --cams pmc_cams
+                e["cameras_per_launch"] = pmc_cams
             if short not in doc["kernels"] or doc["kernels"][short]["avg_ms"] * doc["kernels"][short]["launches"] < ms * calls:
                 doc["kernels"][short] = e              # several instantiations: keep the one that carries the time
     with open(os.path.join(dst_dir, "octree_hbm_traffic.json" if tag != "tmp" else "octree_hbm_traffic_tmp.json"), "w") as g:
@@ -67,4 +69,4 @@ def main(src, dst_dir, tag):
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "profiles",
-         sys.argv[3] if len(sys.argv) > 3 else "r01")
+         sys.argv[3] if len(sys.argv) > 3 else "r01", int(sys.argv[4]) if len(sys.argv) > 4 else 2)

@@ -31,9 +31,14 @@ def main():
     datasets.Dataset.feeder_factory = staticmethod(feeder_for)
     # `python make_trained_twin.py`            the 512 x 300 twin (round 4)
     # `python make_trained_twin.py long`       the 1024 x 1500 twin (round 5: leaves the 14 dB regime, ~24 dB; ~2.5 h on 8 cores)
-    B, steps = (H.TWIN_LONG_RAYS, H.TWIN_LONG_STEPS) if sys.argv[1:] == ["long"] else (H.TWIN_RAYS, H.TWIN_STEPS)
+    # `python make_trained_twin.py long 7`     the same run on 7 threads instead of all cores: another partition of the CPU GEMMs,
+    #                                          i.e. the SAME oracle with another float32 summation order -- its final PSNR against the
+    #                                          fixture's is the oracle's own round-off noise floor (written as a small json, no weights)
+    long_run = sys.argv[1:2] == ["long"]
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    B, steps = (H.TWIN_LONG_RAYS, H.TWIN_LONG_STEPS) if long_run else (H.TWIN_RAYS, H.TWIN_STEPS)
     cfg = O.Cfg()
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     flat0 = O.flatten_params(O.init_params(cfg, seed=20200823))
     p, m, v = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
     rays, px = H.twin_heldout()
@@ -55,6 +60,11 @@ def main():
                torch_version=torch.__version__, threads=torch.get_num_threads(), oracle_s=time.time() - t0,
                trace_steps=np.array(sorted(trace), np.int64), trace_psnr=np.array([trace[k] for k in sorted(trace)], np.float64))
     print({k: v for k, v in out.items() if k != "params"})
+    if len(sys.argv) > 2:
+        import json
+        with open(os.path.join(HERE, f"trained_twin_{B}x{steps}_threads{threads}.json"), "w") as f:
+            json.dump({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in out.items() if k != "params"}, f)
+        return
     np.savez_compressed(os.path.join(HERE, f"trained_twin_{B}x{steps}.npz"), **out)
 
 

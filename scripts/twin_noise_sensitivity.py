@@ -42,6 +42,9 @@ def main():
     feed = [(utils.Rays(*[r.to(dev) for r in b["rays"]]), b["pixels"].to(dev), t.to(dev), u.to(dev), sp.to(dev), lr)
             for _, b, t, u, sp, lr in H.twin_steps(B, steps, cfg)]
     legs = [(0.0, 0)] + [(eps, seed) for eps in (1e-6, 1e-4, 1e-3) for seed in (1, 2, 3)]
+    if os.environ.get("PXO_TWIN_LEGS") == "short":            # A/B of a variant library: the test's four legs
+        legs = [(0.0, 0)] + [(1e-6, seed) for seed in (1, 2, 3)]
+    variant = os.environ.get("PXO_LIB", "")
     for eps, seed in legs:
         model = models.NerfModel(pcfg)
         state = models.TrainState(pcfg, flat0.clone().to(dev))
@@ -56,7 +59,7 @@ def main():
             ops.adam_pack_step(pcfg, state.params, state.m, state.v, state.grads, lr, state.step, state.packed)
             state.step += 1
         out = model.apply(state, drays, False)[1][0].cpu()
-        print(json.dumps({"grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px),
+        print(json.dumps({"library": os.path.basename(variant) or "default", "grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px),
                           "wall_s": round(time.time() - t0, 1)}), flush=True)
 
 

@@ -126,6 +126,8 @@ int pxo_octree_set_lanes_per_ray(int forward, int backward);
 #define PXO_TUNE_GW_MARCHER 0
 #define PXO_TUNE_BWD_CACHE_ROWS 1
 #define PXO_TUNE_BWD_UPDATE 2
+#define PXO_TUNE_GW_TILE_ORDER 3   /* weight mask on power-of-two grids: 0 workgroups take tiles in row-major order (default), 1 the tiles of
+                                      a 4x4-tile square all go to one XCD (one L2); same weights either way (max is order-free) */
 int pxo_octree_set_tuning(int knob, int value);
 int pxo_octree_get_tuning(int knob, int* value);
 

@@ -414,10 +414,39 @@ __global__ void unbrick_max_kernel(const float* __restrict__ bricked, int reso, 
 // voxels above the threshold) 1.97 / 1.29 ms; the same spheres with exact zeros outside (6 % above) 0.95 / 1.08 ms; a NeRF
 // after 105 steps (18 % above) 0.89 / 0.97 ms -- the slab marcher's staging, barriers and flush are paid per brick layer
 // whether or not the rays find anything in it.
+// Which 16x16-pixel tile of which camera a workgroup of the weight-mask launch takes.
+//   order 0  linear: workgroup b -> camera b / tiles, tile b % tiles (row-major); consecutive workgroups go round-robin over
+//            the 8 XCDs, so neighbouring tiles -- which cross the same bricks -- sit behind eight different L2s (PMC: 2.2 GB
+//            read per camera against a floor of 0.46 GB)
+//   order 1  XCD supertiles: the tiles of a 4x4-tile square (64x64 pixels) all go to ONE XCD (workgroup ids that are equal
+//            mod 8), the squares round-robin over the XCDs, so an L2 sees whole squares and every XCD still gets every
+//            part of the image.  The grid is padded (8 * ceil(squares / 8) * 16 workgroups per camera); padding returns at once.
+struct GwTile { int cam, tile; };
+__device__ __forceinline__ GwTile gw_tile(int64_t b, int tiles_x, int tiles_y, int order) {
+  if (order == 0) {
+    const int64_t tiles = (int64_t)tiles_x * tiles_y;
+    return GwTile{(int)(b / tiles), (int)(b % tiles)};
+  }
+  const int super_x = (tiles_x + 3) >> 2, super_y = (tiles_y + 3) >> 2, nsuper = super_x * super_y;
+  const int64_t per_cam = (int64_t)8 * ((nsuper + 7) >> 3) * 16;
+  const int cam = (int)(b / per_cam), r = (int)(b % per_cam);
+  const int xcd = r & 7, idx = r >> 3, sq = xcd + 8 * (idx >> 4), within = idx & 15;
+  if (sq >= nsuper) return GwTile{cam, -1};
+  const int tx = (sq % super_x) * 4 + (within & 3), ty = (sq / super_x) * 4 + (within >> 2);
+  if (tx >= tiles_x || ty >= tiles_y) return GwTile{cam, -1};
+  return GwTile{cam, ty * tiles_x + tx};
+}
+__host__ inline int64_t gw_blocks_per_cam(int tiles_x, int tiles_y, int order) {
+  if (order == 0) return (int64_t)tiles_x * tiles_y;
+  const int nsuper = ((tiles_x + 3) >> 2) * ((tiles_y + 3) >> 2);
+  return (int64_t)8 * ((nsuper + 7) >> 3) * 16;
+}
+
 struct GwSelect {
   const unsigned long long* occupied;   // voxels above sigma_thresh (brick_sigma_kernel)
   int64_t n;                            // voxels
   int force;                            // 1: slab-staged, 0: per-sample, -1: by the occupied fraction
+  int order;                            // gw_tile: 0 linear, 1 XCD supertiles
   __device__ __forceinline__ bool dense() const {
     return force >= 0 ? force != 0 : 2 * (int64_t)*occupied > n;      // more than half of the grid above the threshold
   }
@@ -430,7 +459,10 @@ template <bool BRICK, bool POW2>
 __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma, int reso, const float* __restrict__ c2w_all,
                                                  int n_cams, float fx, float fy, int W, int H, const PxoRenderOpts& opt,
                                                  const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits,
-                                                 uint32_t* __restrict__ s_lut = nullptr) {
+                                                 uint32_t* __restrict__ s_lut = nullptr, int order = 0) {
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const GwTile gt = gw_tile(blockIdx.x, tiles_x, tiles_y, order);
+  if (gt.tile < 0 || gt.cam >= n_cams) return;                 // padding of the supertile order (workgroup-uniform)
   // BRICK && POW2: the bricked index of a voxel is the OR of three per-axis bit patterns; they come from three small LDS
   // tables (s_lut: 3 x kGwLutMax words of workgroup scratch) instead of 13 shift / mask / or instructions per sample.  Filled
   // by the whole workgroup before any thread leaves.
@@ -444,10 +476,7 @@ __device__ __forceinline__ void grid_weight_body(const float* __restrict__ sigma
     __syncthreads();
   }
   // 8x8 pixel tiles per 64-thread wave keep the rays of a wave in neighbouring voxels
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  const int64_t b = blockIdx.x;
-  const int cam = (int)(b / ((int64_t)tiles_x * tiles_y));
-  const int tile = (int)(b % ((int64_t)tiles_x * tiles_y));
+  const int cam = gt.cam, tile = gt.tile;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
   const int py = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -534,12 +563,12 @@ template <int kWin>
 __device__ __forceinline__ void grid_weight_slab_body(const float* __restrict__ sigma, int reso, const float* __restrict__ c2w_all,
                                                       int n_cams, float fx, float fy, int W, int H, const PxoRenderOpts& opt,
                                                       const Vec3& offset, const Vec3& invradius, int* __restrict__ weight_bits,
-                                                      float* __restrict__ s_sigma, int* __restrict__ s_w) {
+                                                      float* __restrict__ s_sigma, int* __restrict__ s_w, int order) {
   __shared__ int s_first;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  const int64_t b = blockIdx.x;
-  const int cam = (int)(b / ((int64_t)tiles_x * tiles_y));
-  const int tile = (int)(b % ((int64_t)tiles_x * tiles_y));
+  const GwTile gt = gw_tile(blockIdx.x, tiles_x, tiles_y, order);
+  if (gt.tile < 0 || gt.cam >= n_cams) return;                 // padding of the supertile order (workgroup-uniform)
+  const int cam = gt.cam, tile = gt.tile;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tx0 = (tile % tiles_x) * 16, ty0 = (tile / tiles_x) * 16;
   const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
@@ -702,9 +731,9 @@ __global__ __launch_bounds__(256) void grid_weight_pow2_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float s_sigma[kWin * kWin * 64];
   __shared__ int s_w[kWin * kWin * 64];
   static_assert(kWin * kWin * 64 >= 3 * kGwLutMax, "the index tables live in the sigma window");
-  if (sel.dense()) grid_weight_slab_body<kWin>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits, s_sigma, s_w);
+  if (sel.dense()) grid_weight_slab_body<kWin>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits, s_sigma, s_w, sel.order);
   else grid_weight_body<true, true>(sigma, reso, c2w_all, n_cams, fx, fy, W, H, opt, offset, invradius, weight_bits,
-                                    reinterpret_cast<uint32_t*>(s_sigma));
+                                    reinterpret_cast<uint32_t*>(s_sigma), sel.order);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1661,6 +1690,7 @@ int pxo_grid_weight_workspace_bytes(int reso, size_t* bytes) {
 }
 
 static int g_gw_marcher = -1;   // -1: chosen on the device; 0 / 1: forced (pxo_octree_set_tuning)
+static int g_gw_tile_order = 0; // gw_tile: 0 linear, 1 XCD supertiles (PXO_TUNE_GW_TILE_ORDER)
 
 int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_all, int n_cams, float fx, float fy,
                            int width, int height, const PxoRenderOpts* opts, const float offset[3],
@@ -1701,9 +1731,12 @@ int pxo_grid_weight_render(const float* sigma_grid, int reso, const float* c2w_a
   // equality test); default -1: chosen on the device by the fraction of voxels above sigma_thresh (GwSelect).  Slab window width measured at 4 / 5 / 6 bricks:
   // 1.245 / 1.257 / 1.262 ms per camera (the staging is not what bounds the marcher); 6 keeps nearly every sample of a tile inside.
   const int force = g_gw_marcher;
-  if (pow2)
-    hipLaunchKernelGGL(grid_weight_pow2_kernel, dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso, c2w_all, n_cams, fx,
-                       fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b), GwSelect{occupied, n, force});
+  if (pow2) {
+    const int64_t per_cam = gw_blocks_per_cam((width + 15) / 16, (height + 15) / 16, g_gw_tile_order);
+    PXO_REQUIRE(per_cam * n_cams < ((int64_t)1 << 31), "pxo_grid_weight_render: too many tiles for one launch");
+    hipLaunchKernelGGL(grid_weight_pow2_kernel, dim3((unsigned)(per_cam * n_cams)), dim3(256), 0, s, (const float*)sigma_b, reso, c2w_all, n_cams, fx,
+                       fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b), GwSelect{occupied, n, force, g_gw_tile_order});
+  }
   else
     hipLaunchKernelGGL((grid_weight_kernel<true, false>), dim3(gw_grid), dim3(256), 0, s, (const float*)sigma_b, reso, c2w_all,
                        n_cams, fx, fy, width, height, *opts, o, ir, reinterpret_cast<int*>(weight_b));
@@ -1791,6 +1824,10 @@ int pxo_octree_set_tuning(int knob, int value) {
                   "pxo_octree_set_tuning: write-combining rows must be 0, 4, 8, 16, 32 or 64 (got %d)", value);
       g_bwd_wc_rows = value;
       return PXO_OK;
+    case PXO_TUNE_GW_TILE_ORDER:
+      PXO_REQUIRE(value == 0 || value == 1, "pxo_octree_set_tuning: weight-mask tile order must be 0 (linear) or 1 (XCD supertiles), got %d", value);
+      g_gw_tile_order = value;
+      return PXO_OK;
     case PXO_TUNE_BWD_UPDATE:
       PXO_REQUIRE(value == 0 || value == 1, "pxo_octree_set_tuning: backward update must be 0 (wave per sample) or 1 (ray-parallel), got %d", value);
       g_bwd_update = value;
@@ -1807,6 +1844,7 @@ int pxo_octree_get_tuning(int knob, int* value) {
     case PXO_TUNE_GW_MARCHER: *value = g_gw_marcher; return PXO_OK;
     case PXO_TUNE_BWD_CACHE_ROWS: *value = g_bwd_wc_rows; return PXO_OK;
     case PXO_TUNE_BWD_UPDATE: *value = g_bwd_update; return PXO_OK;
+    case PXO_TUNE_GW_TILE_ORDER: *value = g_gw_tile_order; return PXO_OK;
     default: set_error("pxo_octree_get_tuning: unknown knob %d", knob); return PXO_ERR_ARG;
   }
 }

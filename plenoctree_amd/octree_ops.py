@@ -152,7 +152,7 @@ def set_lanes_per_ray(forward=0, backward=0):
     check(_lib.load().pxo_octree_set_lanes_per_ray(int(forward), int(backward)), "pxo_octree_set_lanes_per_ray")
 
 
-TUNE_GW_MARCHER, TUNE_BWD_CACHE_ROWS, TUNE_BWD_UPDATE = 0, 1, 2
+TUNE_GW_MARCHER, TUNE_BWD_CACHE_ROWS, TUNE_BWD_UPDATE, TUNE_GW_TILE_ORDER = 0, 1, 2, 3
 
 
 def get_tuning(knob):

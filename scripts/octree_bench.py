@@ -91,7 +91,8 @@ def main():
     a = p.parse_args()
     if a.tune:
         from plenoctree_amd import octree_ops as oops
-        knobs = {"gw_marcher": oops.TUNE_GW_MARCHER, "bwd_cache_rows": oops.TUNE_BWD_CACHE_ROWS, "bwd_update": oops.TUNE_BWD_UPDATE}
+        knobs = {"gw_marcher": oops.TUNE_GW_MARCHER, "bwd_cache_rows": oops.TUNE_BWD_CACHE_ROWS, "bwd_update": oops.TUNE_BWD_UPDATE,
+                 "gw_tile_order": oops.TUNE_GW_TILE_ORDER}
         for kv in a.tune.split(","):
             k, _, v = kv.partition("=")
             oops.set_tuning(knobs[k], int(v))

@@ -2,7 +2,7 @@
 """Weight-mask stage of bench.py's grid512 record (sigma grid of the fixed-seed NeRF after 105 steps, 100 training views
 in one pxo_grid_weight_render call) under several settings of the kernel's run-time switches.
 usage: gw_scene_bench.py "marcher=0" "marcher=1" "" ...   (one timing per argument; "" = chosen on the device;
-marcher -> octree_ops.set_tuning(TUNE_GW_MARCHER, v))"""
+marcher -> octree_ops.set_tuning(TUNE_GW_MARCHER, v), tile_order -> TUNE_GW_TILE_ORDER)"""
 import json
 import os
 import sys
@@ -31,20 +31,20 @@ def main():
     tree = N3Tree(N=2, data_dim=49, init_refine=0, depth_limit=8, radius=radius, center=center, data_format="SH16",
                   map_location=job.device)
     out = [{"sigma_positive_fraction": float((sig > 0).float().mean()), "sigma_gt_1": float((sig > 1).float().mean())}]
+    default_order = oops.get_tuning(oops.TUNE_GW_TILE_ORDER)
     for rep in range(2):
         for st in settings:
             for kv in st.split(","):
                 if kv:
                     k, v = kv.split("=")
-                    assert k == "marcher", k
-                    oops.set_tuning(oops.TUNE_GW_MARCHER, int(v))
+                    oops.set_tuning({"marcher": oops.TUNE_GW_MARCHER, "tile_order": oops.TUNE_GW_TILE_ORDER}[k], int(v))
             job.sync()
             t0 = time.perf_counter()
             w = extraction.calculate_grid_weights(dataset, sig, reso, tree.invradius, tree.offset, 1e-4, comm)
             job.sync()
             dt = time.perf_counter() - t0
             out.append({"setting": st, "rep": rep, "ms": 1e3 * dt, "voxels": int((w >= 1e-3).sum()), "sum": float(w.double().sum())})
-            oops.set_tuning(oops.TUNE_GW_MARCHER, -1)
+            oops.set_tuning(oops.TUNE_GW_MARCHER, -1); oops.set_tuning(oops.TUNE_GW_TILE_ORDER, default_order)
             del w
     for o in out:
         print(json.dumps(o), flush=True)

@@ -160,6 +160,18 @@ def test_grid_weight_render_matches_oracle(reso, W, H, fx):
     with pytest.raises(Exception):
         oops.set_tuning(oops.TUNE_BWD_CACHE_ROWS, 12)            # not an instantiation: rejected, not silently remapped
     assert torch.equal(forced["0"], forced["1"]) and torch.equal(forced["0"], got)
+    # ... and which workgroup takes which tile does not matter either (PXO_TUNE_GW_TILE_ORDER: XCD supertiles, padded grid)
+    if reso % 4 == 0 and (reso & (reso - 1)) == 0:
+        default_order = oops.get_tuning(oops.TUNE_GW_TILE_ORDER)
+        try:
+            for order in (0, 1):
+                for mode in (0, 1):
+                    oops.set_tuning(oops.TUNE_GW_TILE_ORDER, order); oops.set_tuning(oops.TUNE_GW_MARCHER, mode)
+                    w = oops.grid_weight_render(torch.from_numpy(sigma).to(dev), reso, torch.from_numpy(cams).to(dev), fx, fx, W, H,
+                                                oops.render_opts(1e-3), t.offset, t.invradius)
+                    assert torch.equal(w, got), (order, mode)
+        finally:
+            oops.set_tuning(oops.TUNE_GW_TILE_ORDER, default_order); oops.set_tuning(oops.TUNE_GW_MARCHER, -1)
     # accumulating camera by camera == one call (torch.max over cameras, octree/extraction.py:206-212)
     acc = None
     for c in cams:

@@ -329,8 +329,10 @@ int pxo_get_tuning(int knob, int* value);
 /* ---- measurement ------------------------------------------------------------------ */
 /* Diagnostic for contention probes (scripts/contention_probe.py): `blocks` workgroups of `threads` threads that idle for
  * `micros` microseconds of the device's constant-rate clock on `stream` -- what the kernel of a ring all-reduce looks like to
- * the kernels it shares the GPU with (it occupies CU slots and moves no data).  No reference counterpart. */
-int pxo_occupy_cus(int blocks, int threads, float micros, void* stream);
+ * the kernels it shares the GPU with (it occupies CU slots and moves no data).  lds_bytes (0 .. 65536) of dynamic LDS per
+ * workgroup: 0 = a workgroup that fits beside a resident fused-MLP workgroup (133 KB of the CU's 160 KB LDS, 368 of 512
+ * registers per SIMD lane), 64 KB = one that does not and must wait for a CU to become free.  No reference counterpart. */
+int pxo_occupy_cus(int blocks, int threads, float micros, int lds_bytes, void* stream);
 
 /* HIP-event timing of the dominant kernels on the stream they are launched on (bench.py's
  * roofline leg; the reference only has wall-clock rays/sec, nerf_sh/train.py:222-226).

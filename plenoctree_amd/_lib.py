@@ -83,7 +83,7 @@ SIGNATURES = {
     "pxo_cfg_bytes": (c_size_t, []),
     "pxo_set_tuning": (c_int, [c_int, c_int]),
     "pxo_get_tuning": (c_int, [c_int, POINTER(c_int)]),
-    "pxo_occupy_cus": (c_int, [c_int, c_int, c_float, P]),
+    "pxo_occupy_cus": (c_int, [c_int, c_int, c_float, c_int, P]),
     "pxo_tile_rows": (c_int, []),
     "pxo_param_layout": (c_int, [CFG, POINTER(PxoLeaf), POINTER(c_int64)]),
     "pxo_packed_sizes": (c_int, [CFG, POINTER(c_int64), POINTER(c_int64)]),

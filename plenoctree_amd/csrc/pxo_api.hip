@@ -670,15 +670,16 @@ int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, con
                           packed_bwd1, (hipStream_t)stream);
 }
 
-int pxo_occupy_cus(int blocks, int threads, float micros, void* stream) {
+int pxo_occupy_cus(int blocks, int threads, float micros, int lds_bytes, void* stream) {
   PXO_REQUIRE(blocks >= 1 && blocks <= 4096 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && micros >= 0.f &&
-                  micros <= 1e6f,
-              "pxo_occupy_cus: bad arguments (blocks %d, threads %d, micros %g)", blocks, threads, (double)micros);
+                  micros <= 1e6f && lds_bytes >= 0 && lds_bytes <= 65536,
+              "pxo_occupy_cus: bad arguments (blocks %d, threads %d, micros %g, lds_bytes %d)", blocks, threads, (double)micros,
+              lds_bytes);
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
     khz = 100000;                                                    // gfx9: 100 MHz constant clock
   const long long ticks = (long long)((double)micros * 1e-3 * (double)khz);
-  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, ticks);
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, ticks);
   return check_launch("occupy_cus");
 }
 

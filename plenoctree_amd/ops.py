@@ -368,11 +368,12 @@ def get_tuning(knob):
     return v.value
 
 
-def occupy_cus(blocks, threads, micros, stream=None):
-    """pxo_occupy_cus: `blocks` idle workgroups for `micros` us on `stream` (a torch.cuda.Stream; default: the current one)."""
+def occupy_cus(blocks, threads, micros, stream=None, lds_bytes=0):
+    """pxo_occupy_cus: `blocks` idle workgroups (each with `lds_bytes` of LDS) for `micros` us on `stream` (a torch.cuda.Stream;
+    default: the current one)."""
     _require_gpu()
     h = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _stream()
-    check(_lib.load().pxo_occupy_cus(int(blocks), int(threads), float(micros), h), "pxo_occupy_cus")
+    check(_lib.load().pxo_occupy_cus(int(blocks), int(threads), float(micros), int(lds_bytes), h), "pxo_occupy_cus")
 
 
 def profile_enable(on=True, tags=None):

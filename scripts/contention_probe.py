@@ -31,6 +31,9 @@ def main():
     micros = float(os.environ.get("PROBE_US", "50"))
     steps = int(os.environ.get("PROBE_STEPS", "40"))
     rounds = int(os.environ.get("PROBE_ROUNDS", "5"))
+    # 0: the probe's workgroups fit BESIDE a resident fused-MLP workgroup (27 KB of LDS and 144 registers per lane are free on
+    # every CU); 65536: they do not, and can only start on a CU a persistent workgroup has left (a kernel boundary)
+    lds_bytes = int(os.environ.get("PROBE_LDS", "0"))
     default_sched = ops.get_tuning(ops.TUNE_TILE_SCHED)
     a = bench.parse(["--no-extras"])
     out = []
@@ -45,7 +48,7 @@ def main():
         def reducer_for(k):
             def fake_all_reduce(t):
                 if k > 0 and t.numel() == n0:        # bucket 0, on the side stream (current inside GradReducer.reduce)
-                    ops.occupy_cus(k, 256, micros)
+                    ops.occupy_cus(k, 256, micros, lds_bytes=lds_bytes)
             return pdist.GradReducer(pdist.Comm(1, 0, 0, None), dev, all_reduce=fake_all_reduce)
 
         def run(n, red):
@@ -72,7 +75,7 @@ def main():
             base = statistics.median(times[(sched, 0)])
             for k in ks:
                 med = statistics.median(times[(sched, k)])
-                rec = {"rays": B, "tile_sched": "counter" if sched else "static", "probe_workgroups": k, "probe_us": micros,
+                rec = {"rays": B, "tile_sched": "counter" if sched else "static", "probe_workgroups": k, "probe_us": micros, "probe_lds_bytes": lds_bytes,
                        "median_ms_per_step": round(med, 4), "slowdown_us": round(1e3 * (med - base), 1),
                        "runs_ms": [round(x, 4) for x in times[(sched, k)]]}
                 out.append(rec)

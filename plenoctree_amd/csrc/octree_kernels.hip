@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_kernel(RenderArg
 //      rows leave as before (one contiguous row of global atomics per row, the whole wave on it) and the winners write their new
 //      rows themselves; rays that lost an election go round again and usually hit the row the winner has just installed (the
 //      neighbouring pixel entered the same leaf in the same step).  A wave's LDS operations execute in program order, so the
-//      hits of a round land before the evictions read the rows and the installs after.  r05c: 4.70 -> see DESIGN 8.2.
+//      hits of a round land before the evictions read the rows and the installs after.  Measured (r05c): 4.27 / 4.28 ms against
+//      4.26 / 4.29 ms for form 0 -- no gain (the kernel is bound by its evicted rows, not by issue): form 0 stays the default.
 template <int KF, int WC, int UPD = 0>
 __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(RenderArgs A, const float* __restrict__ fwd_rgb,
                                                                              const float* __restrict__ grad_out,

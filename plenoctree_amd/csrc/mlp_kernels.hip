@@ -638,8 +638,8 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 //   static  (DYN = false)  workgroup b runs slots b, b + grid, b + 2 grid, ...
 //   dynamic (DYN = true)   workgroup b runs slot b first and then TAKES slots from a device counter (zero at launch):
 //                          slot = grid + atomicAdd(counter, 1).  The ticket for the NEXT slot is drawn by thread 0 when a
-//                          tile starts and lands in LDS long before the tile ends (a tile is ~200 us, the atomic ~2 us), so
-//                          the schedule costs two LDS barriers per tile.
+//                          tile starts (the atomic's round trip rides with the tile's first loads) and handed over
+//                          through LDS when the tile ends: the schedule costs two LDS barriers per tile.
 // Results do not depend on the schedule: a slot's rows, relu-mask words and bias partial are a function of the slot alone.
 // Why dynamic: with one 8-wave workgroup per CU at the full register / LDS budget nothing else can be co-resident, so a
 // collective's kernel on the high-priority exchange stream (dist.GradReducer) takes whole CUs when it starts at a kernel
@@ -648,11 +648,15 @@ __device__ __forceinline__ void fwd_tile(float* __restrict__ lds, const float* _
 struct TileTicket {
   int* next;                       // LDS word
   unsigned int* counter;           // device word, zero when the launch starts
-  __device__ __forceinline__ void draw(int tid) const {
-    if (tid == 0) *next = (int)gridDim.x + (int)atomicAdd(counter, 1u);
+  // thread 0 draws the ticket when the tile starts and keeps it in a register: the atomic's round trip then overlaps the
+  // tile's first loads (its return is waited for with them) instead of holding thread 0's wave -- and with it the whole
+  // workgroup at the tile's first barrier -- for ~1 us
+  __device__ __forceinline__ int draw(int tid) const {
+    return tid == 0 ? (int)gridDim.x + (int)atomicAdd(counter, 1u) : 0;
   }
-  __device__ __forceinline__ int64_t take() const {
-    lds_barrier();                 // thread 0's ticket is in LDS (and every wave is through the tile)
+  __device__ __forceinline__ int64_t take(int tid, int ticket) const {
+    if (tid == 0) *next = ticket;
+    lds_barrier();                 // the ticket is in LDS (and every wave is through the tile)
     const int v = __builtin_amdgcn_readfirstlane(*next);
     lds_barrier();                 // everyone has read it before thread 0 overwrites it
     return v;
@@ -677,14 +681,15 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
   } else {
     const TileTicket tk{reinterpret_cast<int*>(lds + kTM * kLDA), tile_counter};
     const int64_t n_slots = ts.n_full + ts.n_half;
-    for (int64_t slot = blockIdx.x; slot < n_slots; slot = tk.take()) {
-      tk.draw(tid);
+    for (int64_t slot = blockIdx.x; slot < n_slots;) {
+      const int ticket = tk.draw(tid);
       if (slot < ts.n_full)
         fwd_tile<NHB, SAVE, RGB, kRB>(lds, pk, pts, grid, M, deg, slot * kTM, slot, raw_rgb, raw_sigma, acts, enc_out,
                                       mask, tid, lane, wave);
       else
         fwd_tile<NHB, SAVE, RGB, kRB / 2>(lds, pk, pts, grid, M, deg, ts.half_row0 + (slot - ts.n_full) * (kTM / 2), slot,
                                           raw_rgb, raw_sigma, acts, enc_out, mask, tid, lane, wave);
+      slot = tk.take(tid, ticket);
     }
   }
 }
@@ -908,9 +913,10 @@ __global__ __launch_bounds__(kMlpThreads, kMlpWgPerCu * kMlpWaves / 4) void mlp_
     // the static stride would leave the workgroups that drew few live tiles idle (measured: the kernel at 0.60 of its dense
     // time with 13 % of the rows live).  Results do not depend on the order (per-slot partials, disjoint dz rows).
     const TileTicket tk{nz + kTM / kLiveRows, tile_counter};
-    for (int64_t slot = blockIdx.x; slot < n_slots; slot = tk.take()) {
-      tk.draw(tid);
+    for (int64_t slot = blockIdx.x; slot < n_slots;) {
+      const int ticket = tk.draw(tid);
       run(slot);
+      slot = tk.take(tid, ticket);
     }
   }
 }

@@ -51,6 +51,7 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(1000 + seed)
         ws = state.workspace(ops.train_workspace_bytes(pcfg, B))
         t0 = time.time()
+        trace = {}
         for r, pixels, t_rand, u, sp, lr in feed:
             ops.train_fwd_bwd(pcfg, state.params, state.packed, r.origins, r.directions, r.viewdirs, pixels, state.grads,
                               state.stats, ws, randomized=True, t_rand=t_rand, u=u, sp_points=sp)
@@ -58,8 +59,10 @@ def main():
                 state.grads.mul_(1.0 + eps * torch.randn(state.grads.shape, device=dev, generator=gen))
             ops.adam_pack_step(pcfg, state.params, state.m, state.v, state.grads, lr, state.step, state.packed)
             state.step += 1
+            if state.step % 250 == 0 and state.step < steps:      # the oracle legs print the same checkpoints
+                trace[state.step] = round(H._psnr(model.apply(state, drays, False)[1][0].cpu(), px), 4)
         out = model.apply(state, drays, False)[1][0].cpu()
-        print(json.dumps({"library": os.path.basename(variant) or "default", "grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px),
+        print(json.dumps({"library": os.path.basename(variant) or "default", "grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px), "trace": trace,
                           "wall_s": round(time.time() - t0, 1)}), flush=True)
 
 

@@ -126,11 +126,25 @@ constexpr int kXRows = 64, kXWaves = 4, kXCB = 2, kXWgPerCu = 2;
 constexpr int kXThreads = kXWaves * 64;
 constexpr int kXRB = kXRows / 32;
 
+// The packed image as a raw buffer (see mlp_kernels.hip make_wimage for the hardware assumption: reads past num_records
+// return 0): the (layer, k-group, column block, part) part of a fragment's address is a wave-uniform byte offset in an SGPR, the
+// lane part ONE 32-bit register that never changes -- no 64-bit vector address arithmetic per load, no per-lane pointers held
+// in registers across the GEMMs (round 5: the kernel sat at the 256-VGPR cap with up to 196 B per lane of scratch spills).
+struct X3Image {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff;       // lane * 16
+};
+__device__ __forceinline__ X3Image make_x3image(const float* image, int64_t floats, int lane) {
+  return X3Image{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)(floats * 4), 0x00020000), (uint32_t)lane * 16u};
+}
+// wu: wave-uniform f32x4 index of the first fragment of k-group 0 (of this wave's column blocks) inside the image
 template <int CBN>
-__device__ __forceinline__ void load_w(const f32x4* __restrict__ wp, int64_t kg, int kg_stride, X3Frag (&w)[CBN]) {
+__device__ __forceinline__ void load_w(const X3Image& im, int wu, int kg, int kg_stride, X3Frag (&w)[CBN]) {
 #pragma unroll
   for (int c = 0; c < CBN; ++c) {
-    const f32x4 h = wp[kg * kg_stride + c * 128], l = wp[kg * kg_stride + c * 128 + 64];
+    const int idx = wu + kg * kg_stride + c * 128;
+    const f32x4 h = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(im.rsrc, im.voff, idx * 16, 0));
+    const f32x4 l = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(im.rsrc, im.voff, (idx + 64) * 16, 0));
     __builtin_memcpy(&w[c].hi, &h, 16);
     __builtin_memcpy(&w[c].lo, &l, 16);
   }
@@ -171,17 +185,17 @@ __device__ __forceinline__ void mfma3(const X3Frag (&w)[CBN], const X3Frag (&x)[
 #define PXO_X3_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int RBN, int CBN>
 __device__ __forceinline__ void gemm_x3(const __bf16* __restrict__ xh, const __bf16* __restrict__ xl,
-                                        const f32x4* __restrict__ wp, int kgroups, int avail, bool preloaded, int kg_stride,
+                                        const X3Image& im, int wu, int kgroups, int avail, bool preloaded, int kg_stride,
                                         X3Frag (&w)[4][CBN], f32x16 (&acc)[RBN][CBN]) {
   X3Frag x0[RBN], x1[RBN];
   const int last = avail - 1;
   auto cl = [&](int g) { return g < last ? g : last; };
   if (!preloaded) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) load_w<CBN>(wp, cl(i), kg_stride, w[i]);
+    for (int i = 0; i < 3; ++i) load_w<CBN>(im, wu, cl(i), kg_stride, w[i]);
   }
 #define LOADX(g, x) load_x<RBN>(xh, xl, g, x)
-#define LOADW(g, ww) load_w<CBN>(wp, cl(g), kg_stride, ww)
+#define LOADW(g, ww) load_w<CBN>(im, wu, cl(g), kg_stride, ww)
   load_x<RBN>(xh, xl, 0, x0);
   for (int g = 0; g < kgroups; g += 4) {
     LOADX(g + 1, x1);
@@ -225,9 +239,11 @@ __device__ __forceinline__ float x3_enc_value(float p0, float p1, float p2, int 
   return sinf(xb);
 }
 
-// posenc of the tile's points, split, into planes[:, 0:64]
+// posenc of the tile's points, split, into planes[:, 0:64]; `keep` receives this thread's four 16-byte pieces (hi, lo of its
+// two 8-column halves) so that the skip layer can put them back (posenc_restore_x3) instead of evaluating 16 sinf per point a
+// second time
 __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* __restrict__ pl, const float* __restrict__ pts,
-                                               const X3Grid& grid, int64_t row0, int64_t M, int tid) {
+                                               const X3Grid& grid, int64_t row0, int64_t M, int tid, uint4 (&keep)[4]) {
   static_assert(kXThreads / kXRows == 4, "4 parts x 16 columns");
   const int row = tid % kXRows, part = tid / kXRows;
   const int64_t grow = row0 + row;
@@ -252,8 +268,18 @@ __device__ __forceinline__ void posenc_tile_x3(__bf16* __restrict__ ph, __bf16* 
     for (int i = 0; i < 4; ++i)
       split_bf16_pair(x3_enc_value(p0, p1, p2, part * 16 + h * 8 + 2 * i), x3_enc_value(p0, p1, p2, part * 16 + h * 8 + 2 * i + 1),
                       vh[i], vl[i]);
-    *reinterpret_cast<uint4*>(ph + row * kLDB + part * 16 + h * 8) = make_uint4(vh[0], vh[1], vh[2], vh[3]);
-    *reinterpret_cast<uint4*>(pl + row * kLDB + part * 16 + h * 8) = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+    keep[2 * h] = make_uint4(vh[0], vh[1], vh[2], vh[3]);
+    keep[2 * h + 1] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+    *reinterpret_cast<uint4*>(ph + row * kLDB + part * 16 + h * 8) = keep[2 * h];
+    *reinterpret_cast<uint4*>(pl + row * kLDB + part * 16 + h * 8) = keep[2 * h + 1];
+  }
+}
+__device__ __forceinline__ void posenc_restore_x3(__bf16* __restrict__ ph, __bf16* __restrict__ pl, int tid, const uint4 (&keep)[4]) {
+  const int row = tid % kXRows, part = tid / kXRows;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    *reinterpret_cast<uint4*>(ph + row * kLDB + part * 16 + h * 8) = keep[2 * h];
+    *reinterpret_cast<uint4*>(pl + row * kLDB + part * 16 + h * 8) = keep[2 * h + 1];
   }
 }
 
@@ -278,13 +304,15 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
   for (int i = tid; i < kDepth * kW; i += kXThreads) s_bias[i] = bias[i];
   // this wave's weight stream over the trunk: blocks (kg, cb = wave*kXCB + c, part), 2 x 64 f32x4 per (kg, cb);
   // 4 + 16*4 + 20 + 16*2 = 120 k-groups from layer 0 to layer 7
-  const f32x4* wp0 = reinterpret_cast<const f32x4*>(pk) + (int64_t)(wave * kXCB) * 128 + lane;
+  const X3Image wimg = make_x3image(pk, fwd_image_floats(deg), lane);
+  const int wu0 = (wave * kXCB) * 128;              // f32x4 index of this wave's first column block in a k-group
   constexpr int kTrunkKg = 120;
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * kXRows;
     __syncthreads();   // previous tile's head GEMM has consumed the planes
-    posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
+    uint4 enc_keep[4];
+    posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid, enc_keep);
     __syncthreads();
 
     f32x16 acc[kXRB][kXCB];
@@ -298,14 +326,14 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
       const int nkg = l == 0 ? 4 : 16;
-      gemm_x3<kXRB, kXCB>(xh, xl, wp0 + (int64_t)kg0 * (8 * 128), nkg, kTrunkKg - kg0, l > 0, 8 * 128, w, acc);
+      gemm_x3<kXRB, kXCB>(xh, xl, wimg, wu0 + kg0 * (8 * 128), nkg, kTrunkKg - kg0, l > 0, 8 * 128, w, acc);
       kg0 += nkg;
       if (l == 5) {
-        // skip connection (model_utils.py:70-71): the 64 encoded columns are a second K segment, recomputed in place
+        // skip connection (model_utils.py:70-71): the 64 encoded columns are a second K segment, put back from registers
         __syncthreads();
-        posenc_tile_x3(plane_h, plane_l, pts, grid, row0, M, tid);
+        posenc_restore_x3(plane_h, plane_l, tid, enc_keep);
         __syncthreads();
-        gemm_x3<kXRB, kXCB>(xh, xl, wp0 + (int64_t)kg0 * (8 * 128), 4, kTrunkKg - kg0, true, 8 * 128, w, acc);
+        gemm_x3<kXRB, kXCB>(xh, xl, wimg, wu0 + kg0 * (8 * 128), 4, kTrunkKg - kg0, true, 8 * 128, w, acc);
         kg0 += 4;
       }
       __syncthreads();  // every wave has consumed the input planes
@@ -344,8 +372,8 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
         X3Frag hw[4][1];
 #pragma unroll
         for (int j = 0; j < 16; ++j) hacc[0][0][j] = 0.f;
-        const f32x4* wp = reinterpret_cast<const f32x4*>(pk + fwd_layer_off(8)) + (int64_t)cb * 128 + lane;
-        gemm_x3<1, 1>(xh + rb * 32 * kLDB, xl + rb * 32 * kLDB, wp, 16, 16, false, NHB * 128, hw, hacc);
+        const int wuh = (int)(fwd_layer_off(8) / 4) + cb * 128;
+        gemm_x3<1, 1>(xh + rb * 32 * kLDB, xl + rb * 32 * kLDB, wimg, wuh, 16, 16, false, NHB * 128, hw, hacc);
         const int64_t grow = row0 + rb * 32 + (lane & 31);
         if (grow < M) {
 #pragma unroll

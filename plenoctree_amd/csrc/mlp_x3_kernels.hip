@@ -319,12 +319,19 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
     X3Frag w[4][kXCB];
     int kg0 = 0;          // position of the running layer in the wave's weight stream
     for (int l = 0; l < kDepth; ++l) {
+      // the accumulators start from the bias (register quad q of a lane holds features n0 .. n0 + 3 of one sample, whatever the
+      // row block): the epilogue saves an add per element on the lanes the MFMAs run on
 #pragma unroll
-      for (int r = 0; r < kXRB; ++r)
+      for (int c = 0; c < kXCB; ++c)
 #pragma unroll
-        for (int c = 0; c < kXCB; ++c)
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = (wave * kXCB + c) * 32 + 8 * q + 4 * (lane >> 5);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + l * kW + n0);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+          for (int r = 0; r < kXRB; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[r][c][4 * q + t] = b4[t];
+        }
       const int nkg = l == 0 ? 4 : 16;
       gemm_x3<kXRB, kXCB>(xh, xl, wimg, wu0 + kg0 * (8 * 128), nkg, kTrunkKg - kg0, l > 0, 8 * 128, w, acc);
       kg0 += nkg;
@@ -346,10 +353,9 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int n0 = (wave * kXCB + c) * 32 + 8 * q + 4 * (lane >> 5);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + l * kW + n0);
             uint32_t h01, l01, h23, l23;
-            split_bf16_pair(fmaxf(acc[r][c][4 * q] + b4[0], 0.f), fmaxf(acc[r][c][4 * q + 1] + b4[1], 0.f), h01, l01);
-            split_bf16_pair(fmaxf(acc[r][c][4 * q + 2] + b4[2], 0.f), fmaxf(acc[r][c][4 * q + 3] + b4[3], 0.f), h23, l23);
+            split_bf16_pair(fmaxf(acc[r][c][4 * q], 0.f), fmaxf(acc[r][c][4 * q + 1], 0.f), h01, l01);
+            split_bf16_pair(fmaxf(acc[r][c][4 * q + 2], 0.f), fmaxf(acc[r][c][4 * q + 3], 0.f), h23, l23);
             *reinterpret_cast<uint2*>(plane_h + m * kLDB + n0) = make_uint2(h01, h23);
             *reinterpret_cast<uint2*>(plane_l + m * kLDB + n0) = make_uint2(l01, l23);
           }

@@ -344,34 +344,20 @@ __global__ __launch_bounds__(kXThreads, kXWgPerCu * kXWaves / 4) void mlp_fwd_x3
         kg0 += 4;
       }
       __syncthreads();  // every wave has consumed the input planes
-      // epilogue: register quad q of a lane holds features 8q + 4 (lane >> 5) .. + 3 of sample m.  Written as they are (one
-      // ds_write_b64 per quad and plane) the 32 lanes of a half-wave store 8 bytes each at a row stride of 528 B: rows m, m + 8,
-      // m + 16, m + 24 fall on the same two banks -- 4-way conflicts, 22 % of the kernel's LDS cycles (r05r_x3_pmc.md).  Quads
-      // are therefore paired (q0 = 2p, q1 = 2p + 1) and v_permlane32_swap hands the lower half-wave both halves of q0 and the
-      // upper half-wave both halves of q1: every lane then owns 8 CONSECUTIVE features and stores one 16-byte piece per plane --
-      // the access pattern of the operand reads, which the row stride was chosen to make conflict-free.
+      // epilogue: lane holds features n0 .. n0+3 of sample m per register quad
 #pragma unroll
       for (int r = 0; r < kXRB; ++r) {
         const int m = r * 32 + (lane & 31);
 #pragma unroll
         for (int c = 0; c < kXCB; ++c)
 #pragma unroll
-          for (int p2 = 0; p2 < 2; ++p2) {
-            uint32_t h[2][2], lo[2][2];                        // [quad of the pair][dword]
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int q = 2 * p2 + k;
-              split_bf16_pair(fmaxf(acc[r][c][4 * q], 0.f), fmaxf(acc[r][c][4 * q + 1], 0.f), h[k][0], lo[k][0]);
-              split_bf16_pair(fmaxf(acc[r][c][4 * q + 2], 0.f), fmaxf(acc[r][c][4 * q + 3], 0.f), h[k][1], lo[k][1]);
-            }
-            // swap(a, b): [0] = {a.lower | b.lower}, [1] = {a.upper | b.upper} (lower / upper half-wave)
-            const auto sh0 = __builtin_amdgcn_permlane32_swap(h[0][0], h[1][0], false, false);
-            const auto sh1 = __builtin_amdgcn_permlane32_swap(h[0][1], h[1][1], false, false);
-            const auto sl0 = __builtin_amdgcn_permlane32_swap(lo[0][0], lo[1][0], false, false);
-            const auto sl1 = __builtin_amdgcn_permlane32_swap(lo[0][1], lo[1][1], false, false);
-            const int nb = (wave * kXCB + c) * 32 + 8 * (2 * p2 + (lane >> 5));
-            *reinterpret_cast<uint4*>(plane_h + m * kLDB + nb) = make_uint4(sh0[0], sh1[0], sh0[1], sh1[1]);
-            *reinterpret_cast<uint4*>(plane_l + m * kLDB + nb) = make_uint4(sl0[0], sl1[0], sl0[1], sl1[1]);
+          for (int q = 0; q < 4; ++q) {
+            const int n0 = (wave * kXCB + c) * 32 + 8 * q + 4 * (lane >> 5);
+            uint32_t h01, l01, h23, l23;
+            split_bf16_pair(fmaxf(acc[r][c][4 * q], 0.f), fmaxf(acc[r][c][4 * q + 1], 0.f), h01, l01);
+            split_bf16_pair(fmaxf(acc[r][c][4 * q + 2], 0.f), fmaxf(acc[r][c][4 * q + 3], 0.f), h23, l23);
+            *reinterpret_cast<uint2*>(plane_h + m * kLDB + n0) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(plane_l + m * kLDB + n0) = make_uint2(l01, l23);
           }
       }
       __syncthreads();

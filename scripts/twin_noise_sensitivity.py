@@ -45,6 +45,7 @@ def main():
     if os.environ.get("PXO_TWIN_LEGS") == "short":            # A/B of a variant library: the test's four legs
         legs = [(0.0, 0)] + [(1e-6, seed) for seed in (1, 2, 3)]
     variant = os.environ.get("PXO_LIB", "")
+    torch_adam = os.environ.get("PXO_TWIN_ADAM") == "torch"
     for eps, seed in legs:
         model = models.NerfModel(pcfg)
         state = models.TrainState(pcfg, flat0.clone().to(dev))
@@ -57,12 +58,24 @@ def main():
                               state.stats, ws, randomized=True, t_rand=t_rand, u=u, sp_points=sp)
             if eps > 0:
                 state.grads.mul_(1.0 + eps * torch.randn(state.grads.shape, device=dev, generator=gen))
-            ops.adam_pack_step(pcfg, state.params, state.m, state.v, state.grads, lr, state.step, state.packed)
+            if torch_adam:
+                # component swap: the oracle's Adam (oracle/nerf_oracle.py adam_update, torch float32 ops) on the HIP gradient,
+                # then a plain re-pack of the weight images -- does the optimiser kernel carry the twin's late offset?
+                g = state.grads
+                t = state.step + 1
+                state.m.mul_(0.9).add_(g, alpha=1.0 - 0.9)
+                state.v.mul_(0.999).add_(g * g, alpha=1.0 - 0.999)
+                m_hat = state.m / (1.0 - 0.9 ** t)
+                v_hat = state.v / (1.0 - 0.999 ** t)
+                state.params.sub_(lr * m_hat / (torch.sqrt(v_hat) + 1e-8))
+                state.repack()
+            else:
+                ops.adam_pack_step(pcfg, state.params, state.m, state.v, state.grads, lr, state.step, state.packed)
             state.step += 1
             if state.step % 250 == 0 and state.step < steps:      # the oracle legs print the same checkpoints
                 trace[state.step] = round(H._psnr(model.apply(state, drays, False)[1][0].cpu(), px), 4)
         out = model.apply(state, drays, False)[1][0].cpu()
-        print(json.dumps({"library": os.path.basename(variant) or "default", "grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px), "trace": trace,
+        print(json.dumps({"library": os.path.basename(variant) or "default", "adam": "torch" if torch_adam else "pxo_adam_pack_step", "grad_noise_eps": eps, "noise_seed": seed, "psnr_heldout": H._psnr(out, px), "trace": trace,
                           "wall_s": round(time.time() - t0, 1)}), flush=True)
 
 

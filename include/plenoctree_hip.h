@@ -311,8 +311,9 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
 
 /* ---- run-time choices between implementations of the same result ----------------------- */
-/* Process-wide; results are bit-identical either way (tests/test_gpu_parity.py), only the time differs.  Used by A/B
- * sessions (bench.py --tune) and equality tests; nothing is read from the environment.
+/* Process-wide.  The tile schedule leaves every bit unchanged; the split-K ranges change the (still fixed) order of the
+ * weight-gradient sums, i.e. float32 round-off (tests/test_gpu_parity.py holds both).  Used by A/B sessions (bench.py --tune)
+ * and equality tests; nothing is read from the environment.
  *   PXO_TUNE_TILE_SCHED    how the persistent workgroups of the dense training kernels (mlp_fwd with saved tensors,
  *                          mlp_bwd_data) pick their 128-row tiles inside pxo_train_fwd_bwd*: 0 = static stride,
  *                          1 (default) = from a device counter, so that a workgroup that starts late -- because a
@@ -321,8 +322,8 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
  *   PXO_TUNE_WGRAD_RANGES  row ranges (split-K slabs) per layer of the 256x256 weight-gradient products: 0 = built-in
  *                          choice by pass size, n = exactly n (1 .. number of CUs). */
 #define PXO_TUNE_TILE_SCHED 0
-#define PXO_TUNE_WGRAD_SKINNY_RANGES 2   /* the same for the two skinny products (enc-based pair, heads): 1 .. 2 x number of CUs */
 #define PXO_TUNE_WGRAD_RANGES 1
+#define PXO_TUNE_WGRAD_SKINNY_RANGES 2   /* the same for the two skinny products (enc-based pair, heads): 1 .. 2 x number of CUs */
 int pxo_set_tuning(int knob, int value);
 int pxo_get_tuning(int knob, int* value);
 

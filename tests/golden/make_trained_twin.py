@@ -34,25 +34,31 @@ def main():
     # `python make_trained_twin.py long 7`     the same run on 7 threads instead of all cores: another partition of the CPU GEMMs,
     #                                          i.e. the SAME oracle with another float32 summation order -- its final PSNR against the
     #                                          fixture's is the oracle's own round-off noise floor (written as a small json, no weights)
+    # `python make_trained_twin.py long 8 f64`  the same run in float64 (parameters, moments, rays, randoms): a third evaluation of
+    #                                          the trajectory, free of float32 round-off (json only)
     long_run = sys.argv[1:2] == ["long"]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    f64 = sys.argv[3:4] == ["f64"]
+    dt = torch.float64 if f64 else torch.float32
     B, steps = (H.TWIN_LONG_RAYS, H.TWIN_LONG_STEPS) if long_run else (H.TWIN_RAYS, H.TWIN_STEPS)
     cfg = O.Cfg()
     torch.set_num_threads(threads)
-    flat0 = O.flatten_params(O.init_params(cfg, seed=20200823))
+    flat0 = O.flatten_params(O.init_params(cfg, seed=20200823)).to(dt)
     p, m, v = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
     rays, px = H.twin_heldout()
+    rays = O.Rays(*[r.to(dt) for r in rays])
     t0 = time.time()
     trace = {}
     for step, batch, t_rand, u, sp, lr in H.twin_steps(B, steps, cfg):
-        p, m, v, st, _ = O.train_step(p, m, v, step, O.Rays(*batch["rays"]), batch["pixels"], cfg, t_rand, u, sp, lr)
+        p, m, v, st, _ = O.train_step(p, m, v, step, O.Rays(*[r.to(dt) for r in batch["rays"]]), batch["pixels"].to(dt), cfg,
+                                      t_rand.to(dt), u.to(dt), sp.to(dt), lr)
         if step % 10 == 0:
             print(f"step {step}: loss {float(st['loss']):.5f} psnr {float(st['psnr']):.3f}  ({time.time() - t0:.0f} s)", flush=True)
         if (step + 1) % 250 == 0 and step + 1 < steps:
             with torch.no_grad():
                 trace[step + 1] = H._psnr(O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0], px)
             print(f"held-out PSNR after {step + 1} steps: {trace[step + 1]:.4f} dB", flush=True)
-            np.savez_compressed(f"/tmp/trained_twin_{B}x{steps}_at{step + 1}.npz", params=p.numpy(), m=m.numpy(), v=v.numpy())
+            np.savez_compressed(f"/tmp/trained_twin_{B}x{steps}_t{threads}{'_f64' if f64 else ''}_at{step + 1}.npz", params=p.numpy(), m=m.numpy(), v=v.numpy())
     with torch.no_grad():
         trained = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
         init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]
@@ -62,7 +68,7 @@ def main():
     print({k: v for k, v in out.items() if k != "params"})
     if len(sys.argv) > 2:
         import json
-        with open(os.path.join(HERE, f"trained_twin_{B}x{steps}_threads{threads}.json"), "w") as f:
+        with open(os.path.join(HERE, f"trained_twin_{B}x{steps}_threads{threads}{'_f64' if f64 else ''}.json"), "w") as f:
             json.dump({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in out.items() if k != "params"}, f)
         return
     np.savez_compressed(os.path.join(HERE, f"trained_twin_{B}x{steps}.npz"), **out)

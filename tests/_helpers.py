@@ -229,6 +229,24 @@ TWIN_RAYS, TWIN_STEPS = 512, 300
 TWIN_LONG_RAYS, TWIN_LONG_STEPS = 1024, 1500
 
 
+# the in-test twin of rounds 1-4 (test_trained_psnr_matches_oracle_training): 64 rays x 400 steps, 1000 sparsity points
+TWIN_SHORT_RAYS, TWIN_SHORT_STEPS, TWIN_SHORT_SPARSITY = 64, 400, 1000
+
+
+def twin_short_steps(cfg):
+    """(step, host batch, t_rand, u, sp_points, lr) of the 64 x 400 twin: seeds only, so that the live oracle leg, the
+    committed oracle leg (tests/golden/make_trained_twin.py short) and the HIP leg all replay the same inputs."""
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    B, steps = TWIN_SHORT_RAYS, TWIN_SHORT_STEPS
+    ds = datasets.get_dataset("train", _twin_args(), torch.device("cpu"), batch_size=B)
+    for step in range(steps):
+        batch = next(ds)
+        g = torch.Generator().manual_seed(1000 + step)
+        t_rand = torch.rand(B, 64, generator=g); u = torch.rand(B, 128, generator=g)
+        sp = (torch.rand(TWIN_SHORT_SPARSITY, 3, generator=g) * 2 - 1) * 1.5
+        yield step, batch, t_rand, u, sp, utils.learning_rate_decay(step, 5e-4, 5e-6, steps)
+
+
 def _twin_args():
     from plenoctree_amd.nerf_sh.nerf import utils
     args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])

@@ -814,54 +814,56 @@ def test_mean_over_samples():
         close("leaf mean", out, ref, rtol=1e-5, atol=1e-6)
 
 
-def test_trained_psnr_matches_oracle_training():
+def test_trained_psnr_matches_oracle_training(golden_dir):
     """north_star: PSNR of a HIP-trained model within 0.1 dB of the oracle-trained one.  Both run the same 400 Adam
     steps (64 rays x (64+128) samples + 1000 sparsity points per step, the reference's log-linear lr schedule
     5e-4 -> 5e-6 annealed over the horizon, nerf_sh/nerf/utils.py:483-515) from the same initialisation with identical
-    batches and injected randoms; the result is compared on held-out rays rendered with deterministic sampling.  Over
-    this horizon the held-out PSNR rises by more than 5 dB (10.7 -> ~16 dB), so the 0.1 dB bar is a small fraction
-    of the training signal.  The oracle leg is ~1.5 min of host CPU."""
+    batches and injected randoms (tests/_helpers.py:twin_short_steps -- seeds only); the result is compared on held-out
+    rays rendered with deterministic sampling.  Over this horizon the held-out PSNR rises by more than 5 dB
+    (10.0 -> ~15.5 dB), so the 0.1 dB bar is a small fraction of the training signal.
+
+    The oracle leg (~1.5 min of host CPU) was run once by `tests/golden/make_trained_twin.py short`; its two PSNRs are the
+    fixture trained_twin_64x400.json.  PXO_TWIN_LIVE_ORACLE=1 (or a missing fixture) trains the oracle inside the test
+    instead, step by step next to the HIP leg, as rounds 1-4 did (15.5214 dB on the GPU box, profiles/r05i_trained_psnr.json)."""
     ops = _ops(); dev = _gpu()
-    from plenoctree_amd.nerf_sh.nerf import datasets, models, utils
-    cfg = O.Cfg(sparsity_npoints=1000)
+    import json
+    from _helpers import TWIN_SHORT_RAYS, TWIN_SHORT_SPARSITY, TWIN_SHORT_STEPS, twin_heldout, twin_short_steps
+    from plenoctree_amd.nerf_sh.nerf import models, utils
+    cfg = O.Cfg(sparsity_npoints=TWIN_SHORT_SPARSITY)
     pcfg = pxo_cfg(ops, cfg)
-    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
-    utils.update_flags(args); args.factor = 8
-    B, steps = 64, 400
-    ds = datasets.get_dataset("train", args, torch.device("cpu"), batch_size=B)
+    fixture = os.path.join(golden_dir, f"trained_twin_{TWIN_SHORT_RAYS}x{TWIN_SHORT_STEPS}.json")
+    live = os.environ.get("PXO_TWIN_LIVE_ORACLE", "0") == "1" or not os.path.exists(fixture)
     flat0 = O.flatten_params(O.init_params(cfg, seed=20200823))
     model = models.NerfModel(pcfg)
     state = models.TrainState(pcfg, flat0.clone().to(dev))
     p, m, v = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    for step in range(steps):
-        batch = next(ds)
-        g = torch.Generator().manual_seed(1000 + step)
-        t_rand = torch.rand(B, 64, generator=g); u = torch.rand(B, 128, generator=g)
-        sp = (torch.rand(1000, 3, generator=g) * 2 - 1) * 1.5
-        lr = utils.learning_rate_decay(step, 5e-4, 5e-6, steps)
-        rays = O.Rays(*batch["rays"])
-        p, m, v, _, _ = O.train_step(p, m, v, step, rays, batch["pixels"], cfg, t_rand, u, sp, lr)
+    for step, batch, t_rand, u, sp, lr in twin_short_steps(cfg):
+        if live:
+            p, m, v, _, _ = O.train_step(p, m, v, step, O.Rays(*batch["rays"]), batch["pixels"], cfg, t_rand, u, sp, lr)
         dbatch = {"rays": utils.Rays(*[r.to(dev) for r in batch["rays"]]), "pixels": batch["pixels"].to(dev)}
         models.train_step(model, state, dbatch, lr, t_rand=t_rand.to(dev), u=u.to(dev), sp_points=sp.to(dev))
-    test_ds = datasets.get_dataset("test", args, torch.device("cpu"))
-    views = [test_ds.get_image(i) for i in (0, 67, 133)]                 # three held-out views, every 4th pixel
-    rays = O.Rays(*[torch.cat([t["rays"][k].reshape(-1, 3)[::4] for t in views]).contiguous() for k in range(3)])
-    px = torch.cat([t["pixels"].reshape(-1, 3)[::4] for t in views])
+    rays, px = twin_heldout()                                            # three held-out views, every 4th pixel
     with torch.no_grad():
-        ref = O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0]
-        init = O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0]
+        if live:
+            psnr_ref = _psnr(O.render(O.unflatten_params(p, cfg), rays, cfg)[1][0], px)
+            psnr_init = _psnr(O.render(O.unflatten_params(flat0, cfg), rays, cfg)[1][0], px)
+        else:
+            with open(fixture) as f:
+                g = json.load(f)
+            assert (g["rays_per_step"], g["steps"], g["sparsity_npoints"]) == (TWIN_SHORT_RAYS, TWIN_SHORT_STEPS, TWIN_SHORT_SPARSITY)
+            psnr_ref, psnr_init = float(g["psnr_trained"]), float(g["psnr_init"])
         # HIP-trained weights through the float64 oracle: the arbiter of same-weights render parity
         rays64 = O.Rays(*[r.double() for r in rays])
         cross = O.render(O.unflatten_params(state.params.cpu().double(), cfg), rays64, cfg)[1][0]
     out = model.apply(state, utils.Rays(*[r.to(dev) for r in rays]), False)[1][0].cpu()
-    psnr_ref, psnr_hip, psnr_init, psnr_cross = _psnr(ref, px), _psnr(out, px), _psnr(init, px), _psnr(cross, px)
+    psnr_hip, psnr_cross = _psnr(out, px), _psnr(cross, px)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "trained_psnr.json"), "w") as f:
-            f.write('{"steps": %d, "rays_per_step": %d, "psnr_init": %.4f, "psnr_oracle_trained": %.4f, '
+            f.write('{"steps": %d, "rays_per_step": %d, "oracle_leg": "%s", "psnr_init": %.4f, "psnr_oracle_trained": %.4f, '
                     '"psnr_hip_trained": %.4f, "psnr_hip_trained_oracle_rendered": %.4f}\n'
-                    % (steps, B, psnr_init, psnr_ref, psnr_hip, psnr_cross))
+                    % (TWIN_SHORT_STEPS, TWIN_SHORT_RAYS, "live" if live else "fixture", psnr_init, psnr_ref, psnr_hip, psnr_cross))
     assert psnr_ref > psnr_init + 4.0, (psnr_ref, psnr_init)      # the horizon carries a real training signal
     assert abs(psnr_hip - psnr_ref) <= 0.1, (psnr_hip, psnr_ref)
     assert abs(psnr_hip - psnr_cross) <= 1e-4, (psnr_hip, psnr_cross)   # same TRAINED weights: render parity at north_star's bar

@@ -61,7 +61,7 @@ typedef struct PxoCfg {
   float sparsity_length;       /* 0.05 */
   float sparsity_radius;       /* 1.5 */
   float weight_decay_mult;     /* 0 */
-  int32_t mlp_precision;       /* PXO_MLP_F32 (0, default) or PXO_MLP_BF16X3: INFERENCE-ONLY opt-in, see below */
+  int32_t mlp_precision;       /* PXO_MLP_F32 (0, default); opt-ins: PXO_MLP_BF16X3 (inference only), PXO_MLP_BF16X6, see below */
   float noise_std;             /* 0 = the reference's None (every preset); > 0: add_gaussian_noise on raw sigma of the ray
                                   samples when randomized (nerf_sh/nerf/models.py:258-264,318-324) */
   int32_t skip_zero_rows;      /* pxo_train_fwd_bwd only.  1: sample rows whose upstream gradient (d loss / d raw_rgb, d raw_sigma) is
@@ -76,9 +76,16 @@ typedef struct PxoCfg {
  * reported throughput use it).  PXO_MLP_BF16X3: the forward-only entry points (pxo_eval_points, pxo_grid_sigma,
  * pxo_render_fwd, pxo_mlp_fwd without saved tensors) evaluate each product as hi*hi + hi*lo + lo*hi of bf16 splits with
  * float32 accumulation (csrc/mlp_x3_kernels.hip); pxo_pack_weights then writes the split image (same size) and takes
- * packed_bwd == NULL; pxo_train_fwd_bwd and the saved-tensor form of pxo_mlp_fwd return PXO_ERR_UNSUPPORTED. */
+ * packed_bwd == NULL; pxo_train_fwd_bwd and the saved-tensor form of pxo_mlp_fwd return PXO_ERR_UNSUPPORTED.
+ * PXO_MLP_BF16X6: float32-ACCURATE split precision for the whole path, training included (csrc/mlp_x6_kernels.hip): every
+ * float32 operand of the fused MLP forward and backward(data) is split exactly into three bf16 parts and a product is the six
+ * partial products of order <= 2^-16 with float32 accumulation (6/16 of the float32 MFMA time; per GEMM at least as close to
+ * the float64 product as the float32 MFMA kernels, tests/test_gpu_x6.py).  Saved tensors, gradients and the weight-gradient
+ * GEMMs stay float32; pxo_packed_sizes / pxo_pack_weights then describe / write the three-part images (1.5 x the size), both
+ * directions.  Opt-in: the headline throughput and every roofline figure of bench.py are PXO_MLP_F32. */
 #define PXO_MLP_F32 0
 #define PXO_MLP_BF16X3 1
+#define PXO_MLP_BF16X6 2
 
 /* One leaf of the parameter arena (offsets in floats, relative to ONE MLP's sub-arena). */
 typedef struct PxoLeaf {
@@ -90,10 +97,11 @@ typedef struct PxoLeaf {
 } PxoLeaf;
 
 /* ABI version of this header: bumped whenever a struct gains a field or an entry point changes meaning (5: PxoCfg has
- * noise_std + skip_zero_rows, pxo_profile_enable takes a tag MASK, pxo_set_tuning / pxo_occupy_cus exist).  A binding checks
+ * noise_std + skip_zero_rows, pxo_profile_enable takes a tag MASK, pxo_set_tuning / pxo_occupy_cus exist; 6: PXO_MLP_BF16X6,
+ * pxo_adam_pack_step serves every precision).  A binding checks
  * pxo_version() == PXO_ABI_VERSION and pxo_cfg_bytes() == sizeof(PxoCfg) after dlopen (plenoctree_amd/_lib.py does): a
  * caller built against an older header would otherwise pass a short PxoCfg and have its tail read from past the end. */
-#define PXO_ABI_VERSION 5
+#define PXO_ABI_VERSION 6
 const char* pxo_last_error(void);
 int pxo_version(void);
 size_t pxo_cfg_bytes(void);
@@ -238,7 +246,9 @@ int pxo_adam_step(float* params, float* m, float* v, const float* grads, int64_t
 /* The same update of the whole 2-MLP arena AND the refresh of the four fragment-ordered images in one launch
  * (state.optimizer.apply_gradient + the re-pack that must follow it): equals pxo_adam_step followed by
  * pxo_pack_weights on both MLPs, bit for bit.  The images must have been written by pxo_pack_weights once (their
- * zero padding is not rewritten); packed_bwd0/1 may both be NULL.  float32 images only. */
+ * zero padding is not rewritten); packed_bwd0/1 may both be NULL.  With a split-precision cfg the same call runs the Adam
+ * kernel and then the packing kernels of that precision (two or three launches instead of one, same results as the separate
+ * calls). */
 int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, const float* grads, float lr,
                        int64_t step, float grad_scale, float* packed_fwd0, float* packed_bwd0,
                        float* packed_fwd1, float* packed_bwd1, void* stream);

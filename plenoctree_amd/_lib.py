@@ -16,7 +16,7 @@ NET_WIDTH = 256
 ENC_DIM = 63
 ENC_PAD = 64
 NUM_LEAVES = 20
-MLP_F32, MLP_BF16X3 = 0, 1
+MLP_F32, MLP_BF16X3, MLP_BF16X6 = 0, 1, 2
 
 
 class PxoError(RuntimeError):
@@ -70,7 +70,7 @@ class PxoCamera(Structure):
 
 
 TREE_MAX_DEPTH = 10
-ABI_VERSION = 5                     # PXO_ABI_VERSION of include/plenoctree_hip.h
+ABI_VERSION = 6                     # PXO_ABI_VERSION of include/plenoctree_hip.h
 
 P = c_void_p
 CFG = POINTER(PxoCfg)

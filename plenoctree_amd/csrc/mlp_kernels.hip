@@ -92,6 +92,7 @@ __global__ void pack_bwd_kernel(const float* __restrict__ p, int deg, float* __r
 }
 
 int launch_pack(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X6) return launch_pack_x6(cfg, mlp_params, fwd, bwd, s);
   if (cfg->mlp_precision == PXO_MLP_BF16X3) {
     if (bwd) { set_error("pack_weights: mlp_precision bf16x3 is forward-only (packed_bwd must be NULL)"); return PXO_ERR_UNSUPPORTED; }
     return launch_pack_x3(cfg, mlp_params, fwd, s);
@@ -740,6 +741,8 @@ static int launch_fwd_any(const PxoCfg* cfg, const float* pk, const float* pts, 
 int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int64_t M,
                    float* raw_rgb, float* raw_sigma, float* acts, float* enc, uint32_t* mask,
                    hipStream_t s, unsigned int* tile_counter) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X6)
+    return launch_mlp_fwd_x6(cfg, packed_fwd, pts, 0, 0, nullptr, nullptr, M, raw_rgb, raw_sigma, acts, enc, mask, tile_counter, s);
   if (cfg->mlp_precision == PXO_MLP_BF16X3) {
     if (acts || enc || mask) { set_error("mlp_fwd: mlp_precision bf16x3 is inference-only (no saved tensors)"); return PXO_ERR_UNSUPPORTED; }
     return launch_mlp_fwd_x3(cfg, packed_fwd, pts, 0, 0, nullptr, nullptr, M, raw_rgb, raw_sigma, s);
@@ -752,6 +755,9 @@ int launch_mlp_fwd(const PxoCfg* cfg, const float* packed_fwd, const float* pts,
 
 int launch_mlp_fwd_grid(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0, int x1,
                         const float* off, const float* scale, float* sigma_out, hipStream_t s) {
+  if (cfg->mlp_precision == PXO_MLP_BF16X6)
+    return launch_mlp_fwd_x6(cfg, packed_fwd, nullptr, reso, x0, off, scale, (int64_t)(x1 - x0) * reso * reso, nullptr, sigma_out,
+                             nullptr, nullptr, nullptr, nullptr, s);
   if (cfg->mlp_precision == PXO_MLP_BF16X3)
     return launch_mlp_fwd_x3(cfg, packed_fwd, nullptr, reso, x0, off, scale, (int64_t)(x1 - x0) * reso * reso, nullptr,
                              sigma_out, s);
@@ -935,6 +941,9 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
     set_error("mlp_bwd_data: hipMemsetAsync(tile counter) failed");
     return PXO_ERR_HIP;
   }
+  if (cfg->mlp_precision == PXO_MLP_BF16X6)
+    return launch_mlp_bwd_data_x6(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, dz, dbias_partial, chunk_live, tile_counter, s);
+  if (cfg->mlp_precision != PXO_MLP_F32) { set_error("mlp_bwd_data: mlp_precision bf16x3 is inference-only"); return PXO_ERR_UNSUPPORTED; }
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);
   const TileSched ts = tile_sched(M, grid_dim.x);

@@ -62,8 +62,8 @@ int validate_cfg(const PxoCfg* cfg) {
               cfg->num_coarse_samples);
   PXO_REQUIRE(cfg->num_fine_samples >= 0 && cfg->num_coarse_samples + cfg->num_fine_samples <= 256,
               "num_coarse_samples+num_fine_samples must be <= 256");
-  PXO_REQUIRE(cfg->mlp_precision == PXO_MLP_F32 || cfg->mlp_precision == PXO_MLP_BF16X3, "mlp_precision %d unknown",
-              cfg->mlp_precision);
+  PXO_REQUIRE(cfg->mlp_precision == PXO_MLP_F32 || cfg->mlp_precision == PXO_MLP_BF16X3 || cfg->mlp_precision == PXO_MLP_BF16X6,
+              "mlp_precision %d unknown", cfg->mlp_precision);
   PXO_REQUIRE(cfg->noise_std >= 0.f, "noise_std %g < 0 (0 = None)", (double)cfg->noise_std);
   PXO_REQUIRE(cfg->skip_zero_rows == 0 || cfg->skip_zero_rows == 1, "skip_zero_rows %d is not 0 / 1", cfg->skip_zero_rows);
   return PXO_OK;
@@ -310,8 +310,9 @@ int pxo_param_layout(const PxoCfg* cfg, PxoLeaf* leaves, int64_t* floats_per_mlp
 
 int pxo_packed_sizes(const PxoCfg* cfg, int64_t* fwd_floats, int64_t* bwd_floats) {
   PXO_TRY(validate_cfg(cfg));
-  if (fwd_floats) *fwd_floats = fwd_image_floats(cfg->sh_deg);
-  if (bwd_floats) *bwd_floats = bwd_image_floats(cfg->sh_deg);
+  const bool x6 = cfg->mlp_precision == PXO_MLP_BF16X6;
+  if (fwd_floats) *fwd_floats = x6 ? x6_fwd_image_floats(cfg->sh_deg) : fwd_image_floats(cfg->sh_deg);
+  if (bwd_floats) *bwd_floats = x6 ? x6_bwd_image_floats(cfg->sh_deg) : bwd_image_floats(cfg->sh_deg);
   return PXO_OK;
 }
 
@@ -535,8 +536,8 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   PXO_REQUIRE(B >= 1 && params && packed_fwd0 && packed_bwd0 && origins && directions && viewdirs && pixels && grads &&
                   stats && ws,
               "pxo_train_fwd_bwd: bad arguments");
-  if (cfg->mlp_precision != PXO_MLP_F32) {
-    set_error("pxo_train_fwd_bwd: training runs in float32 only (mlp_precision must be PXO_MLP_F32)");
+  if (cfg->mlp_precision != PXO_MLP_F32 && cfg->mlp_precision != PXO_MLP_BF16X6) {
+    set_error("pxo_train_fwd_bwd: training runs in float32 or its float32-accurate bf16x6 emulation only (mlp_precision bf16x3 is an inference option)");
     return PXO_ERR_UNSUPPORTED;
   }
   if (cfg->num_fine_samples > 0) PXO_REQUIRE(packed_fwd1 && packed_bwd1, "pxo_train_fwd_bwd: MLP_1 images missing");
@@ -663,8 +664,15 @@ int pxo_adam_pack_step(const PxoCfg* cfg, float* params, float* m, float* v, con
   PXO_REQUIRE(params && m && v && grads && step >= 0 && packed_fwd0 && packed_fwd1, "pxo_adam_pack_step: bad arguments");
   PXO_REQUIRE((packed_bwd0 != nullptr) == (packed_bwd1 != nullptr), "pxo_adam_pack_step: both backward images or none");
   if (cfg->mlp_precision != PXO_MLP_F32) {
-    set_error("pxo_adam_pack_step: the split-precision images are inference-only (use pxo_adam_step + pxo_pack_weights)");
-    return PXO_ERR_UNSUPPORTED;
+    // split-precision images: the Adam kernel, then that precision's packing kernels (same results as the separate calls)
+    if (cfg->mlp_precision == PXO_MLP_BF16X3 && packed_bwd0) {
+      set_error("pxo_adam_pack_step: the bf16x3 images are forward-only (packed_bwd must be NULL)");
+      return PXO_ERR_UNSUPPORTED;
+    }
+    const int64_t n_mlp = mlp_param_count(cfg->sh_deg);
+    PXO_TRY(launch_adam(params, m, v, grads, 2 * n_mlp, lr, step, grad_scale, (hipStream_t)stream));
+    PXO_TRY(launch_pack(cfg, params, packed_fwd0, packed_bwd0, (hipStream_t)stream));
+    return launch_pack(cfg, params + n_mlp, packed_fwd1, packed_bwd1, (hipStream_t)stream);
   }
   return launch_adam_pack(cfg, params, m, v, grads, lr, step, grad_scale, packed_fwd0, packed_bwd0, packed_fwd1,
                           packed_bwd1, (hipStream_t)stream);

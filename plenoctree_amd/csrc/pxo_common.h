@@ -81,6 +81,29 @@ __host__ __device__ inline int64_t bwd_layer_off(int l, int deg) {  // l in 1..7
 }
 __host__ __device__ inline int64_t bwd_image_floats(int deg) { return bwd_layer_off(0, deg); }
 
+// ---- bf16x6 images (mlp_x6_kernels.hip; PxoCfg.mlp_precision = PXO_MLP_BF16X6) ---------------------------------------
+// Every weight is split into three bf16 parts w = w1 + w2 + w3; a (16-deep k-group, 32-column block) is stored as three
+// fragments [w1 | w2 | w3] of 64 lanes x 16 B (8 bf16: k = 16 kg + 8 (lane >> 5) + e, column 32 cb + (lane & 31)).
+// Offsets below are in 4-byte slots, like the float32 images'.
+constexpr int kX6KgSlots = 8 * 3 * 256;       // slots per k-group of a 256-column layer
+__host__ __device__ inline int x6_fwd_kg(int l) { return l == 0 ? 4 : (l == 5 ? 20 : 16); }
+__host__ __device__ inline int64_t x6_fwd_layer_off(int l) {  // l in 0..8 (8 = heads)
+  int64_t off = 0;
+  for (int i = 0; i < l; ++i) off += (int64_t)x6_fwd_kg(i) * kX6KgSlots;
+  return off;
+}
+__host__ __device__ inline int64_t x6_fwd_bias_off(int deg) {
+  return x6_fwd_layer_off(8) + (int64_t)16 * head_blocks(deg) * 3 * 256;
+}
+__host__ __device__ inline int64_t x6_fwd_image_floats(int deg) {
+  return x6_fwd_bias_off(deg) + 8 * kW + 32 * head_blocks(deg);
+}
+// backward(data): head^T (K = the head columns, zero-padded to whole groups of 4 k-groups), then W_l^T for l = 7..1
+__host__ __device__ inline int x6_bwd_head_kg(int deg) { return 4 * ((head_blocks(deg) + 1) / 2); }
+__host__ __device__ inline int64_t x6_bwd_image_floats(int deg) {
+  return (int64_t)(x6_bwd_head_kg(deg) + 7 * 16) * kX6KgSlots;
+}
+
 __host__ __device__ inline int64_t num_tiles(int64_t M) { return (M + kTM - 1) / kTM; }
 
 // Tile schedule of one fused-MLP launch over M rows on `grid` persistent workgroups (the same function of (M, grid)
@@ -182,6 +205,15 @@ int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
 int launch_pack_x3(const PxoCfg* cfg, const float* mlp_params, float* fwd, hipStream_t s);
 int launch_mlp_fwd_x3(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int reso, int x0, const float* off,
                       const float* scale, int64_t M, float* raw_rgb, float* raw_sigma, hipStream_t s);
+
+// opt-in float32-accurate split-precision training kernels (mlp_x6_kernels.hip); pts == nullptr selects the dense-grid source
+int launch_pack_x6(const PxoCfg* cfg, const float* mlp_params, float* fwd, float* bwd, hipStream_t s);
+int launch_mlp_fwd_x6(const PxoCfg* cfg, const float* packed_fwd, const float* pts, int reso, int x0, const float* off,
+                      const float* scale, int64_t M, float* raw_rgb, float* raw_sigma, float* acts, float* enc,
+                      uint32_t* mask, unsigned int* tile_counter, hipStream_t s);
+int launch_mlp_bwd_data_x6(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
+                           const uint32_t* mask, int64_t M, float* dz, float* dbias_partial, uint8_t* chunk_live,
+                           unsigned int* tile_counter, hipStream_t s);
 
 int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_,
                              float far_, int lindisp, const float* t_rand, float* z, float* pts,

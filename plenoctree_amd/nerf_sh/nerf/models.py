@@ -41,7 +41,7 @@ class TrainState:
 
     def repack(self, need_bwd=True):
         """Refresh the fragment-ordered images after a parameter update."""
-        need_bwd = need_bwd and self.cfg.mlp_precision == 0      # the split-precision images are forward-only
+        need_bwd = need_bwd and self.cfg.mlp_precision != ops._lib.MLP_BF16X3      # the bf16x3 images are forward-only
         for i in range(2):
             f, b = self.packed[i] if self.packed[i] is not None else (None, None)
             self.packed[i] = ops.pack_weights(self.cfg, self.mlp_params(i), f, b, need_bwd=need_bwd)
@@ -103,7 +103,7 @@ def make_cfg(args):
                         sparsity_npoints=args.sparsity_npoints, near_=args.near, far_=args.far,
                         sparsity_weight=args.sparsity_weight, sparsity_length=args.sparsity_length,
                         sparsity_radius=args.sparsity_radius, weight_decay_mult=args.weight_decay_mult,
-                        mlp_precision=1 if getattr(args, "mlp_precision", "f32") == "bf16x3" else 0,
+                        mlp_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[getattr(args, "mlp_precision", "f32")],
                         noise_std=0.0 if getattr(args, "noise_std", None) is None else args.noise_std,
                         skip_zero_rows=int(bool(getattr(args, "skip_zero_rows", False))))
 

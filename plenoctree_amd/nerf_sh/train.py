@@ -22,8 +22,9 @@ def main(argv=None):
     torch.cuda.set_device(comm.local_rank)
     device = torch.device("cuda", comm.local_rank)
     utils.check_flags(args, require_batch_size_div=True, world_size=comm.world)
-    if args.mlp_precision != "f32":
-        raise ValueError("--mlp_precision bf16x3 is an inference option (eval / gen_video / extraction); training runs in float32")
+    if args.mlp_precision == "bf16x3":
+        raise ValueError("--mlp_precision bf16x3 is an inference option (eval / gen_video / extraction); training runs in float32 "
+                         "or in its float32-accurate emulation bf16x6")
     h0 = comm.rank == 0
     render_dir = os.path.join(args.train_dir, "render")
     timings_file = None

@@ -5,6 +5,7 @@
 #   bench      python bench.py $BENCH_ARGS                     -> gpurun_out/bench.json
 #   prof       rocprofv3 --kernel-trace --stats of the headline bench (+ gap analysis)   -> gpurun_out/prof
 #   pmc        four rocprofv3 --pmc passes of the same command (own runs, no trace domains) -> gpurun_out/pmc{1..4}
+#              (PMC_CMD="python scripts/x6_probe.py --variants x6 --steps 2": the passes of another command; PMC_TAG names the summary)
 #   timeline   per-step kernel timelines at the batch sizes in $BATCHES (default 512)      -> gpurun_out/timeline_b*.txt
 #   ab_trees   bench.py alternately in the trees $TREES ("_ab_base ." default), ROUNDS x per batch -> gpurun_out/ab_trees.txt
 #   ab_env     run-time / variant-library A/B of ONE tree: VARIANTS="name|ENV=v ENV2=v|bench args;..." -> gpurun_out/$AB_TAG.txt
@@ -74,10 +75,17 @@ for stage in ${STAGES:-tests bench}; do
     cd /tmp; i=0
     for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
       i=$((i+1))
-      timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 $PROF_HEAD_ARGS > /dev/null 2> "$R/gpurun_out/pmc$i.err"
+      if [ -n "${PMC_CMD:-}" ]; then
+        ( cd "$R" && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- $PMC_CMD > /dev/null 2> "$R/gpurun_out/pmc$i.err" )
+      else
+        timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 $PROF_HEAD_ARGS > /dev/null 2> "$R/gpurun_out/pmc$i.err"
+      fi
       echo "pmc pass $i exit $?"
     done
-    cd "$R"; find gpurun_out -name "*.csv" -size +30M -delete ;;
+    cd "$R"; find gpurun_out -name "*.csv" -size +30M -delete
+    # a summary on the box (the full CSVs can exceed what is merged back); hbm_traffic.json of a custom command is not the bench's
+    mkdir -p gpurun_out/pmc_summary && python scripts/summarize_prof.py gpurun_out gpurun_out/pmc_summary ${PMC_TAG:-pmc} > /dev/null
+    cat gpurun_out/pmc_summary/${PMC_TAG:-pmc}_pmc.md ;;
   timeline)
     for B in ${BATCHES:-512}; do
       timeout 300 python bench.py --batch $B --steps 40 --warmup 5 $HEAD_ARGS ${TL_ARGS:-} > gpurun_out/bench_b$B.json 2> gpurun_out/bench_b$B.err

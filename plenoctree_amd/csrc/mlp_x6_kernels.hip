@@ -49,19 +49,24 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
   c = (__bf16)(r - (float)b);
 }
 // the same for a pair, packed [lo half = first | hi half = second]: v_cvt_pk_bf16_f32, widened back with a shift / a mask
+// (the residuals as 2-vectors: v_pk_add_f32, one instruction per pair)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(f32x2 x) {
+  const bf16x2 h = {(__bf16)x[0], (__bf16)x[1]};
+  uint32_t b;
+  __builtin_memcpy(&b, &h, 4);
+  asm volatile("" : "+v"(b));     // ONE v_cvt_pk_bf16_f32: without this the low half is converted a second time for `b << 16`
+  return b;
+}
+__device__ __forceinline__ f32x2 widen_pk_bf16(uint32_t b) { return f32x2{__uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)}; }
+__device__ __forceinline__ void split3_pair(f32x2 x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = cvt_pk_bf16(x);
+  const f32x2 r = x - widen_pk_bf16(p1);
+  p2 = cvt_pk_bf16(r);
+  p3 = cvt_pk_bf16(r - widen_pk_bf16(p2));
+}
 __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
-  uint32_t hb;
-  __builtin_memcpy(&hb, &h, 4);
-  const float ra = a - __uint_as_float(hb << 16), rb = b - __uint_as_float(hb & 0xffff0000u);
-  const bf16x2 m = {(__bf16)ra, (__bf16)rb};
-  uint32_t mb;
-  __builtin_memcpy(&mb, &m, 4);
-  const float sa = ra - __uint_as_float(mb << 16), sb = rb - __uint_as_float(mb & 0xffff0000u);
-  const bf16x2 l = {(__bf16)sa, (__bf16)sb};
-  __builtin_memcpy(&p3, &l, 4);
-  p1 = hb;
-  p2 = mb;
+  split3_pair(f32x2{a, b}, p1, p2, p3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -203,6 +208,20 @@ __device__ __forceinline__ void mfma6(const X6W& w, const X6X<RBN>& x, f32x16 (&
   PXO_X6_MFMA(lo, 1, 1);
   PXO_X6_MFMA(lo, 1, 0);
   PXO_X6_MFMA(lo, 0, 1);
+}
+// the first k-group of a layer: the leading chain starts from `init` (the bias pattern: srcC is another register set, no
+// copies), the correction chain from the inline constant 0
+template <int RBN>
+__device__ __forceinline__ void mfma6_first(const X6W& w, const X6X<RBN>& x, const f32x16& init, f32x16 (&hi)[RBN], f32x16 (&lo)[RBN]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[0], x.p[r][0], init, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < RBN; ++r) lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[2], x.p[r][0], zero, 0, 0, 0);
+  PXO_X6_MFMA(lo, 0, 2);
+  PXO_X6_MFMA(lo, 1, 1);
+  PXO_X6_MFMA(lo, 1, 0);
+  PXO_X6_MFMA(lo, 0, 1);
 #undef PXO_X6_MFMA
 }
 
@@ -216,9 +235,11 @@ __device__ __forceinline__ void mfma6(const X6W& w, const X6X<RBN>& x, f32x16 (&
 __device__ __forceinline__ void lds_barrier6() {       // orders LDS traffic only (see mlp_kernels.hip lds_barrier)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-template <int RBN>
+// INIT: the accumulators are written, not read, by the first k-group (hi starts from *init, lo from 0)
+template <int RBN, bool INIT = false>
 __device__ __forceinline__ void gemm_x6(const __bf16* __restrict__ xp, const X6Image& im, int wu, int kgroups, int avail,
-                                        bool preloaded, int kg_stride, X6W (&w)[4], f32x16 (&hi)[RBN], f32x16 (&lo)[RBN]) {
+                                        bool preloaded, int kg_stride, X6W (&w)[4], f32x16 (&hi)[RBN], f32x16 (&lo)[RBN],
+                                        const f32x16* init = nullptr) {
   X6X<RBN> x0, x1;
   const int last = avail - 1;
   auto cl = [&](int g) { return g < last ? g : last; };
@@ -231,7 +252,8 @@ __device__ __forceinline__ void gemm_x6(const __bf16* __restrict__ xp, const X6I
     load_x6<RBN>(xp, g + 1, x1);
     load_w6(im, wu, cl(g + 3), kg_stride, w[3]);
     PXO_X6_PIN();
-    mfma6<RBN>(w[0], x0, hi, lo);
+    if (INIT && g == 0) mfma6_first<RBN>(w[0], x0, *init, hi, lo);
+    else mfma6<RBN>(w[0], x0, hi, lo);
     PXO_X6_PIN();
     load_x6<RBN>(xp, g + 2, x0);
     load_w6(im, wu, cl(g + 4), kg_stride, w[0]);
@@ -255,13 +277,54 @@ __device__ __forceinline__ void gemm_x6(const __bf16* __restrict__ xp, const X6I
 __device__ __forceinline__ void mask_push6(uint32_t& mw, float v) {
   asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mw) : "v"(v) : "vcc");
 }
+// relu(s) and its mask bit from one compare: v = s > 0 ? s : 0, mw = 2 mw + (s > 0).  The condition lives in its own SGPR pair
+// (VOP3 forms), not in VCC: consecutive elements do not serialise on one register and the compiler may interleave them.
+__device__ __forceinline__ float relu_push6(uint32_t& mw, float s) {
+  float v;
+  unsigned long long c;
+  asm("v_cmp_lt_f32 %1, 0, %3\n\tv_cndmask_b32 %0, 0, %3, %1\n\tv_addc_co_u32 %2, %1, %2, %2, %1"
+      : "=&v"(v), "=&s"(c), "+v"(mw) : "v"(s));
+  return v;
+}
 __device__ __forceinline__ float mask_pop6(uint32_t& mw, float x) {
   float r;
-  asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc" : "+v"(mw), "=v"(r) : "v"(x) : "vcc");
+  unsigned long long c;
+  asm("v_add_co_u32 %0, %2, %0, %0\n\tv_cndmask_b32 %1, 0, %3, %2" : "+v"(mw), "=&v"(r), "=&s"(c) : "v"(x));
   return r;
 }
 
-// the three planes' 8-byte pieces of four consecutive features of one sample
+// the three planes' 8-byte pieces of four consecutive features of one sample, computed ahead of the barrier that frees the planes
+struct X6Quad { uint2 p[3]; };
+__device__ __forceinline__ X6Quad split_quad(f32x2 v01, f32x2 v23) {
+  X6Quad o;
+  split3_pair(v01, o.p[0].x, o.p[1].x, o.p[2].x);
+  split3_pair(v23, o.p[0].y, o.p[1].y, o.p[2].y);
+  return o;
+}
+// Written as they are (one ds_write_b64 per quad and plane) the 32 lanes of a half-wave store 8 bytes each at a row stride of
+// 528 B: rows m and m + 16 fall on the same banks, and the 98 KB a layer writes take 1600 cycles with every matrix pipe idle
+// (profiles/r06a_x6_phases.txt).  Quads are therefore paired (2p, 2p + 1) and v_permlane32_swap hands the lower half-wave both
+// halves of quad 2p and the upper half-wave both halves of quad 2p + 1: every lane owns 8 CONSECUTIVE features and stores one
+// 16-byte piece per plane -- the access pattern of the operand reads, which the row stride makes conflict-free.
+struct X6Chunk { uint4 p[3]; };
+__device__ __forceinline__ X6Chunk pair_quads(const X6Quad& a, const X6Quad& b) {
+  X6Chunk o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    // swap(a, b): [0] = {a.lower | b.lower}, [1] = {a.upper | b.upper} (lower / upper half-wave)
+    const auto sx = __builtin_amdgcn_permlane32_swap(a.p[i].x, b.p[i].x, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(a.p[i].y, b.p[i].y, false, false);
+    o.p[i] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+  }
+  return o;
+}
+// e01 / e2: this lane's element offset in plane 0 / plane 2 (its own register: beyond the ds_write immediate range; an opaque
+// INTEGER so that the access stays an LDS access -- an opaque pointer loses its address space and becomes a flat store)
+__device__ __forceinline__ void store_chunk(__bf16* __restrict__ planes, int e01, int e2, int off, const X6Chunk& o) {
+  *reinterpret_cast<uint4*>(planes + e01 + off) = o.p[0];
+  *reinterpret_cast<uint4*>(planes + e01 + kPlane + off) = o.p[1];
+  *reinterpret_cast<uint4*>(planes + e2 + off) = o.p[2];
+}
 __device__ __forceinline__ void store_planes4(__bf16* __restrict__ planes, int off, float v0, float v1, float v2, float v3) {
   uint32_t a01, b01, c01, a23, b23, c23;
   split3_pair(v0, v1, a01, b01, c01);
@@ -370,6 +433,12 @@ __device__ __forceinline__ void fwd_subtile_x6(__bf16* __restrict__ planes, cons
   constexpr int kTrunkKg = 4 + 16 * 4 + 20 + 16 * 2;   // 120 k-groups from layer 0 to layer 7
   constexpr int kKgStride = kX6KgSlots / 4;
   const int64_t rows = M - row0 < kYRows ? M - row0 : kYRows;
+  // where this lane's quads go: element (row = 32 r + (lane & 31), feature = 32 wave + 8 q + 4 (lane >> 5)) -- one register each
+  // for the row-major global copy and for planes 0-1 / plane 2 (beyond the ds_write immediate range); (r, q) are immediates
+  const uint32_t st_voff = (uint32_t)((lane & 31) * kW + wave * 32 + 4 * (lane >> 5)) * 4u;
+  const int pw = (lane & 31) * kLDB + wave * 32 + 8 * (lane >> 5);      // plane pieces: features 32 wave + 16 p + 8 (lane >> 5) .. + 7
+  int pw2 = pw + 2 * kPlane;
+  asm volatile("" : "+v"(pw2));
 
   lds_barrier6();   // the previous sub-tile's head GEMM has consumed the planes
   uint4 enc_keep[3];
@@ -380,18 +449,17 @@ __device__ __forceinline__ void fwd_subtile_x6(__bf16* __restrict__ planes, cons
   X6W w[4];
   int kg0 = 0;          // position of the running layer in the wave's weight stream
   for (int l = 0; l < kDepth; ++l) {
-    // the leading accumulators start from the bias (register quad q of a lane holds features n0 .. n0 + 3 of one sample)
+    // the leading chain starts from the bias (register quad q of a lane holds features n0 .. n0 + 3 of one sample, whatever
+    // the row block): the first k-group's MFMAs take it as srcC
+    f32x16 binit;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + l * kW + n0);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + l * kW + wave * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
-      for (int r = 0; r < kYRB; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { hi[r][4 * q + t] = b4[t]; lo[r][4 * q + t] = 0.f; }
+      for (int t = 0; t < 4; ++t) binit[4 * q + t] = b4[t];
     }
     const int nkg = l == 0 ? 4 : 16;
-    gemm_x6<kYRB>(xp, wimg, wu0 + kg0 * kKgStride, nkg, kTrunkKg - kg0, l > 0, kKgStride, w, hi, lo);
+    gemm_x6<kYRB, true>(xp, wimg, wu0 + kg0 * kKgStride, nkg, kTrunkKg - kg0, l > 0, kKgStride, w, hi, lo, &binit);
     kg0 += nkg;
     if (l == 5) {
       // skip connection (model_utils.py:70-71): the 64 encoded columns are a second K segment, put back from registers
@@ -401,62 +469,103 @@ __device__ __forceinline__ void fwd_subtile_x6(__bf16* __restrict__ planes, cons
       gemm_x6<kYRB>(xp, wimg, wu0 + kg0 * kKgStride, 4, kTrunkKg - kg0, true, kKgStride, w, hi, lo);
       kg0 += 4;
     }
-    lds_barrier6();  // every wave has consumed the input planes
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63;
-    uint32_t mw = 0u;
-    const __amdgpu_buffer_rsrc_t out =
-        __builtin_amdgcn_make_buffer_rsrc(SAVE ? acts + ((int64_t)l * M + row0) * kW : nullptr, 0, SAVE ? (int)(rows * kW * 4) : 0, 0x00020000);
+    if (l == kDepth - 1) {
+      // the head slice's first weight fragments travel during this layer's epilogue (see the heads below)
+      constexpr int NJ = RGB ? NHB : 1, NS = NHB == 3 ? 2 : 4, KS = 16 / NS;
+      if (wave < NJ * NS) {
+        const int wuh = (int)(x6_fwd_layer_off(8) / 4) + (RGB ? wave % NJ : NHB - 1) * (3 * 64) + (wave / NJ) * KS * (NHB * 3 * 64);
 #pragma unroll
-    for (int r = 0; r < kYRB; ++r) {
-      const int m = r * 32 + (lane_e & 31);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n0 = wave * 32 + 8 * q + 4 * (lane_e >> 5);
-        f32x4 v;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          v[t] = fmaxf(hi[r][4 * q + t] + lo[r][4 * q + t], 0.f);
-          if (SAVE) mask_push6(mw, v[t]);
-        }
-        if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out, (uint32_t)(m * kW + n0) * 4u, 0, 0);
-        store_planes4(planes, m * kLDB + n0, v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 3; ++i) load_w6(wimg, wuh, i, NHB * 3 * 64, w[i]);
       }
     }
-    if (SAVE) mask_sub[(int64_t)l * (2 * kYThreads) + 2 * tid_e] = mw;
+    // Epilogue, first half -- registers and global memory only, so it needs no barrier: a wave that is through its GEMM does
+    // this vector work while slower waves still feed the matrix pipe.  relu + mask bit, the float32 copy for the weight
+    // gradients, the exact three-way split.
+    uint32_t mwr[kYRB] = {0u, 0u};                   // one mask chain per row block (16 bits each), joined below
+    const __amdgpu_buffer_rsrc_t out =
+        __builtin_amdgcn_make_buffer_rsrc(SAVE ? acts + ((int64_t)l * M + row0) * kW : nullptr, 0, SAVE ? (int)(rows * kW * 4) : 0, 0x00020000);
+    X6Chunk pc[kYRB][2];
+#pragma unroll
+    for (int r = 0; r < kYRB; ++r) {
+      X6Quad pq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 s01 = f32x2{hi[r][4 * q], hi[r][4 * q + 1]} + f32x2{lo[r][4 * q], lo[r][4 * q + 1]};
+        const f32x2 s23 = f32x2{hi[r][4 * q + 2], hi[r][4 * q + 3]} + f32x2{lo[r][4 * q + 2], lo[r][4 * q + 3]};
+        f32x4 v;
+        if (SAVE) {
+          v[0] = relu_push6(mwr[r], s01[0]); v[1] = relu_push6(mwr[r], s01[1]);
+          v[2] = relu_push6(mwr[r], s23[0]); v[3] = relu_push6(mwr[r], s23[1]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out, st_voff, (r * 32 * kW + 8 * q) * 4, 0);
+        } else {
+          v[0] = fmaxf(s01[0], 0.f); v[1] = fmaxf(s01[1], 0.f); v[2] = fmaxf(s23[0], 0.f); v[3] = fmaxf(s23[1], 0.f);
+        }
+        pq[q] = split_quad(f32x2{v[0], v[1]}, f32x2{v[2], v[3]});
+      }
+      pc[r][0] = pair_quads(pq[0], pq[1]);
+      pc[r][1] = pair_quads(pq[2], pq[3]);
+    }
+    if (SAVE) mask_sub[(int64_t)l * (2 * kYThreads) + 2 * tid] = (mwr[0] << 16) | mwr[1];
+    lds_barrier6();  // every wave has consumed the input planes
+#pragma unroll
+    for (int r = 0; r < kYRB; ++r)
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) store_chunk(planes, pw, pw2, r * 32 * kLDB + 16 * p2, pc[r][p2]);
     lds_barrier6();
   }
 
-  // heads (model_utils.py:72-74, :91-93): wave w owns row block w % 2 and head blocks w / 2, + 4, ...; sigma only
-  // (RGB = false): the block that holds column C
+  // heads (model_utils.py:72-74, :91-93): [raw_rgb | raw_sigma] = h7 @ [Dense_9 | Dense_8] + b.  The 32-column head blocks are too
+  // few for 8 waves, and one block per wave with one row block per MFMA chain is bound by the L2 latency of its weight
+  // fragments (12.8 k cycles per sub-tile, profiles/r06a_x6_phases.txt).  So K is cut into slices: wave w multiplies BOTH row
+  // blocks by head block w % NJ over k-groups [KS (w / NJ), + KS) -- 12 MFMAs per weight fragment like the trunk, its first
+  // fragments fetched before the last trunk epilogue -- the partial sums meet in LDS (the planes are free by then) and are
+  // added in slice order, with the bias, by the thread that writes the output.
   {
-    constexpr int CSTEP = kYWaves / kYRB;               // waves per row block (4)
-    constexpr int HMAX = RGB ? (NHB + CSTEP - 1) / CSTEP : 1;
-    const int rb = wave % kYRB, cb0 = wave / kYRB;
+    constexpr int NJ = RGB ? NHB : 1;                    // head blocks computed (sigma only: the block that holds column C)
+    constexpr int NS = NHB == 3 ? 2 : 4;                 // K slices (by NHB, not NJ: sigma-only sums in the same order)
+    constexpr int KS = 16 / NS;                          // k-groups per slice
+    const bool active = wave < NJ * NS;
+    const int cbj = wave % NJ, ks = wave / NJ;
+    const int cb = RGB ? cbj : NHB - 1;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const int wuh = (int)(x6_fwd_layer_off(8) / 4) + cb * (3 * 64) + ks * KS * (NHB * 3 * 64);
+      gemm_x6<kYRB, true>(xp + ks * KS * 16, wimg, wuh, KS, KS, true, NHB * 3 * 64, w, hi, lo, &zero16);
+    }
+    // partial sums in LDS as [slice][row][head column] (row stride RS floats), written as the 16-byte quads the lanes hold and
+    // read back row-major: the sub-tile's rows of raw_rgb are ONE contiguous block of global memory, written coalesced
+    constexpr int RS = NJ * 32 + 4;
+    float* red = reinterpret_cast<float*>(planes);
+    lds_barrier6();                                      // every wave is through with the planes
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < kYRB; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {hi[r][4 * q] + lo[r][4 * q], hi[r][4 * q + 1] + lo[r][4 * q + 1], hi[r][4 * q + 2] + lo[r][4 * q + 2],
+                           hi[r][4 * q + 3] + lo[r][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(red + (ks * kYRows + r * 32 + (lane & 31)) * RS + cbj * 32 + 8 * q + 4 * (lane >> 5)) = v;
+        }
+    }
+    lds_barrier6();
     const float* hb = bias + 8 * kW;
-#pragma unroll 1
-    for (int i = 0; i < HMAX; ++i) {
-      const int cb = RGB ? cb0 + i * CSTEP : (cb0 == 0 ? NHB - 1 : NHB);
-      if (cb >= NHB) continue;                           // wave-uniform
-      f32x16 hh[1], hl[1];
-      X6W hw[4];
+    const int col0 = (RGB ? 0 : NHB - 1) * 32;           // head column of the first staged column
+    if (RGB) {
+      const int n_out = (int)rows * C;
+      float* dst = raw_rgb + row0 * C;
+      for (int o = tid; o < n_out; o += kYThreads) {
+        const int row = o / C, col = o - row * C;
+        float v = red[row * RS + col];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { hh[0][j] = 0.f; hl[0][j] = 0.f; }
-      const int wuh = (int)(x6_fwd_layer_off(8) / 4) + cb * (3 * 64);
-      gemm_x6<1>(xp + rb * 32 * kLDB, wimg, wuh, 16, 16, false, NHB * 3 * 64, hw, hh, hl);
-      const int64_t grow = row0 + rb * 32 + (lane & 31);
-      if (grow < M) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int col = cb * 32 + 8 * q + 4 * (lane >> 5) + t;
-            const float v = hh[0][4 * q + t] + hl[0][4 * q + t] + hb[col];
-            if (col < C) { if (RGB) raw_rgb[grow * C + col] = v; }
-            else if (col == C) raw_sigma[grow] = v;
-          }
+        for (int k = 1; k < NS; ++k) v += red[(k * kYRows + row) * RS + col];
+        dst[o] = v + hb[col];
       }
+    }
+    if (tid < rows) {                                    // sigma: head column C
+      float v = red[tid * RS + C - col0];
+#pragma unroll
+      for (int k = 1; k < NS; ++k) v += red[(k * kYRows + tid) * RS + C - col0];
+      raw_sigma[row0 + tid] = v + hb[C];
     }
   }
 }
@@ -581,6 +690,12 @@ __device__ __forceinline__ bool bwd_subtile_x6(__bf16* __restrict__ planes, floa
   const X6Image wimg = make_x6image(pkb, x6_bwd_image_floats(deg), lane);
   const int wu0 = wave * (3 * 64);
   const int64_t rows = M - row0 < kYRows ? M - row0 : kYRows;
+  const uint32_t st_voff = (uint32_t)((lane & 31) * kW + wave * 32 + 4 * (lane >> 5)) * 4u;     // see fwd_subtile_x6
+  const int pw = (lane & 31) * kLDB + wave * 32 + 8 * (lane >> 5);      // plane pieces: features 32 wave + 16 p + 8 (lane >> 5) .. + 7
+  int pw2 = pw + 2 * kPlane;
+  asm volatile("" : "+v"(pw2));
+  // this lane's bias accumulators: lane 31 / 63 of a wave writes the sums of features 32 wave + 4 (lane >> 5) + 8 q + t
+  float* dbp = db_acc + wave * 32 + 4 * (lane >> 5);
 
   lds_barrier6();   // the previous sub-tile is through with the planes, the staging tile and nz
   if (SKIP && tid < kChunks) nz[tid] = 0;
@@ -632,55 +747,58 @@ __device__ __forceinline__ bool bwd_subtile_x6(__bf16* __restrict__ planes, floa
 
   f32x16 hi[kYRB], lo[kYRB];
   X6W w[4];
-  auto zero = [&]() {
-#pragma unroll
-    for (int r = 0; r < kYRB; ++r)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) { hi[r][j] = 0.f; lo[r][j] = 0.f; }
-  };
-  zero();
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint32_t mw = mask_sub[(int64_t)(kDepth - 1) * (2 * kYThreads) + 2 * tid];   // relu mask of the layer the running GEMM produces
   int kg0 = 0;
-  gemm_x6<kYRB>(xp, wimg, wu0, HK, kStreamKg, false, kKgStride, w, hi, lo);
+  gemm_x6<kYRB, true>(xp, wimg, wu0, HK, kStreamKg, false, kKgStride, w, hi, lo, &zero16);
   kg0 += HK;
   for (int l = kDepth - 1; l >= 0; --l) {
-    lds_barrier6();  // every wave has consumed the planes this wave is about to rewrite
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63;
+    // Epilogue, first half -- registers, global memory and this lane's own bias accumulators only: no barrier needed, so a
+    // wave that is through its GEMM does this vector work while the other wave of its SIMD still feeds the matrix pipe
     const __amdgpu_buffer_rsrc_t out =
         __builtin_amdgcn_make_buffer_rsrc(dz + ((int64_t)l * M + row0) * kW, 0, (int)(rows * kW * 4), 0x00020000);
-    float cs[16];
+    f32x2 cs[8];
+    X6Chunk pc[kYRB][2];
+    uint32_t mwr[kYRB] = {mw, mw << 16};             // one mask chain per row block (MSB first)
 #pragma unroll
     for (int r = 0; r < kYRB; ++r) {
-      const int m = r * 32 + (lane_e & 31);
+      X6Quad pq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n0 = wave * 32 + 8 * q + 4 * (lane_e >> 5);
-        f32x4 v;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          v[t] = mask_pop6(mw, hi[r][4 * q + t] + lo[r][4 * q + t]);
-          cs[4 * q + t] = r == 0 ? v[t] : cs[4 * q + t] + v[t];
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out, (uint32_t)(m * kW + n0) * 4u, 0, 0);
-        if (l > 0) store_planes4(planes, m * kLDB + n0, v[0], v[1], v[2], v[3]);
+        const f32x2 s01 = f32x2{hi[r][4 * q], hi[r][4 * q + 1]} + f32x2{lo[r][4 * q], lo[r][4 * q + 1]};
+        const f32x2 s23 = f32x2{hi[r][4 * q + 2], hi[r][4 * q + 3]} + f32x2{lo[r][4 * q + 2], lo[r][4 * q + 3]};
+        f32x2 v01, v23;
+        v01[0] = mask_pop6(mwr[r], s01[0]); v01[1] = mask_pop6(mwr[r], s01[1]);
+        v23[0] = mask_pop6(mwr[r], s23[0]); v23[1] = mask_pop6(mwr[r], s23[1]);
+        cs[2 * q] = r == 0 ? v01 : cs[2 * q] + v01;
+        cs[2 * q + 1] = r == 0 ? v23 : cs[2 * q + 1] + v23;
+        const f32x4 v = {v01[0], v01[1], v23[0], v23[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out, st_voff, (r * 32 * kW + 8 * q) * 4, 0);
+        if (l > 0) pq[q] = split_quad(v01, v23);
+      }
+      if (l > 0) {
+        pc[r][0] = pair_quads(pq[0], pq[1]);
+        pc[r][1] = pair_quads(pq[2], pq[3]);
       }
     }
     // bias gradient of layer l: column sums over the sub-tile's samples (= lanes), fixed order
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float s = sum_half_wave(cs[i]);
-      if ((lane_e & 31) == 31) {
-        float* p = db_acc + l * kW + wave * 32 + 8 * (i >> 2) + 4 * (lane_e >> 5) + (i & 3);
-        *p = accumulate ? *p + s : s;
+      const float sum = sum_half_wave(cs[i >> 1][i & 1]);
+      if ((lane & 31) == 31) {
+        float* p = dbp + l * kW + 8 * (i >> 2) + (i & 3);
+        *p = accumulate ? *p + sum : sum;
       }
     }
-    lds_barrier6();
+    if (l > 0) mw = mask_sub[(int64_t)(l - 1) * (2 * kYThreads) + 2 * tid];     // next layer's mask, fetched under the GEMM
+    lds_barrier6();  // every wave has consumed the planes (and, at l == 0, the slot's bias sums are complete)
     if (l == 0) break;
-    zero();
-    mw = mask_sub[(int64_t)(l - 1) * (2 * kYThreads) + 2 * tid_e];     // next layer's mask, fetched under the GEMM
-    gemm_x6<kYRB>(xp, wimg, wu0 + kg0 * kKgStride, 16, kStreamKg - kg0, true, kKgStride, w, hi, lo);
+#pragma unroll
+    for (int r = 0; r < kYRB; ++r)
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) store_chunk(planes, pw, pw2, r * 32 * kLDB + 16 * p2, pc[r][p2]);
+    lds_barrier6();
+    gemm_x6<kYRB, true>(xp, wimg, wu0 + kg0 * kKgStride, 16, kStreamKg - kg0, true, kKgStride, w, hi, lo, &zero16);
     kg0 += 16;
   }
   return true;

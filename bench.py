@@ -13,7 +13,10 @@ MLP_1's half + stats at the end), Adam + weight re-pack.  Rank 0 prints ONE JSON
 carries records of the other BASELINE configs and of the metric's second half:
 `converge` (eval PSNR on held-out 800x800 views after a fixed training budget), `strong512` (configs[2] strong-scaling
 shape), `tt_sh25` (configs[3] shape), `coarse64` (configs[0] shape: 64 coarse samples only), `render_fwd` (the eval
-path), `grid512` (configs[4]) and `octree` (the PlenOctree-side kernels with their HBM rooflines).
+path), `grid512` (configs[4]), `octree` (the PlenOctree-side kernels with their HBM rooflines) and the two
+opt-in split-precision records (`opt_in_bf16x3_inference`; `opt_in_bf16x6_training`: the float32-ACCURATE emulation of the two
+fused MLP kernels on the bf16 matrix pipe -- its own record, `dtype` "f32 (bf16x6 emulated)"; `value`, `roofline` and every
+other record stay on native float32).
 
 `--backend gloo` is a DRY RUN of this file's multi-rank control flow on CPU ranks for tests/test_bench_dry_run_cpu.py,
 which installs oracle-backed stand-ins for the HIP entry points first (the product has no CPU path: without the
@@ -39,7 +42,7 @@ FLOP_TRAIN_PER_RAY_COARSE_ONLY = {3: 189.2e6, 4: 191.9e6}
 FLOP_RENDER_PER_RAY = {3: 257.8e6, 4: 261.4e6}
 FLOP_SIGMA_PER_POINT = 982528                        # trunk + sigma head only (131.9 TFLOP at 512^3)
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "octree", "bf16x3", "coarse64", "tt_sh25")
+ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "octree", "bf16x3", "bf16x6", "coarse64", "tt_sh25")
 
 
 def parse(argv=None):
@@ -370,6 +373,16 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, even
     return out
 
 
+def x6_state_twin(tr):
+    """(model, state) at the SAME parameters / Adam moments / step with PxoCfg.mlp_precision = bf16x6 (its own weight images)."""
+    from plenoctree_amd.nerf_sh.nerf import models
+    cfg = type(tr["model"].cfg).from_buffer_copy(tr["model"].cfg)
+    cfg.mlp_precision = 2
+    st = models.TrainState(cfg, tr["state"].params.clone(), step=tr["state"].step)
+    st.m.copy_(tr["state"].m); st.v.copy_(tr["state"].v)
+    return models.NerfModel(cfg), st
+
+
 def run_converge(job, a):
     """The second half of BASELINE.json's metric: eval PSNR.  A fixed training budget from the fixed-seed initialisation
     (`--converge-steps` steps of `--batch` rays per GPU, the headline's step), then render_image of held-out views of the
@@ -421,6 +434,27 @@ def run_converge(job, a):
         sparse.update(live_chunk_fraction=live / max(total, 1), steps_each=k, after_steps=s0,
                       note="opt-in PxoCfg.skip_zero_rows: rows with an exactly zero upstream gradient skipped in 16-row chunks; "
                            "gradients bit-identical to the dense pass; scene-dependent, not part of any other record")
+        if "bf16x6" in a.extras.split(",") and not a.no_extras:
+            # the same trained state through the opt-in bf16x6 kernels (its own weight images), dense and skipping
+            from plenoctree_amd.nerf_sh.nerf import models, utils
+            m6, s6 = x6_state_twin(tr)
+            reducer = job.reducer()
+
+            def steps6(first, n):
+                job.sync()
+                t = time.perf_counter()
+                for s_ in range(first, first + n):
+                    lr = utils.learning_rate_decay(s_, tr["args"].lr_init, tr["args"].lr_final, tr["args"].max_steps)
+                    models.train_step(m6, s6, next(tr["dataset"]), lr, randomized=True, seed=(s_ << 8) | job.rank,
+                                      world_size=job.world, reducer=reducer)
+                job.sync()
+                return tr["per_gpu"] * job.world * n / job.max_over_ranks(time.perf_counter() - t)
+            steps6(s0, 3)
+            sparse["bf16x6_dense_rays_per_s"] = steps6(s0 + 3, k)
+            m6.cfg.skip_zero_rows = 1
+            steps6(s0 + 3 + k, 3)
+            sparse["bf16x6_skip_zero_rows_rays_per_s"] = steps6(s0 + 6 + k, k)
+            m6, s6 = None, None
     return {"eval_psnr": sum(psnrs) / len(psnrs), "sparse_backward": sparse, "eval_psnr_per_view": psnrs, "views": n_views,
             "view_size": [test.h, test.w], "train_steps": a.converge_steps, "rays_per_step": tr["per_gpu"] * job.world,
             "train_s": t_train, "train_rays_per_s": tr["per_gpu"] * job.world * a.converge_steps / t_train,
@@ -465,6 +499,26 @@ def run_coarse64(job, a):
                               "frac": v / job.world * FLOP_TRAIN_PER_RAY_COARSE_ONLY[t["deg"]] / (PEAK_F32_MFMA_TFLOPS * 1e12)}
     out["workload"] = "64 coarse samples per ray, no fine level (SURVEY 8d: 189.2 MFLOP per ray), 10k sparsity points"
     return out
+
+
+def run_x6(job, a, f32_head):
+    """Opt-in PxoCfg.mlp_precision = bf16x6 (csrc/mlp_x6_kernels.hip): the headline's step with the fused MLP forward (saved
+    tensors) and backward(data) evaluated as six bf16 partial products per float32 product, float32 accumulation, everything
+    that leaves the kernels float32, weight-gradient GEMMs native float32.  Same batches, same seeds, dense reverse pass."""
+    k = max(20, a.steps // 2) if job.cuda else a.steps
+    t = run_train(job, a.preset, k, 3 if job.cuda else 1, mlp_precision="bf16x6")
+    v = t["per_gpu"] * job.world * k / t["elapsed"]
+    rec = {"value": v, "unit": "rays/s", "dtype": "f32 (bf16x6 emulated)", "steps": k, "ms_per_step": 1e3 * t["elapsed"] / k,
+           "vs_f32_headline": v / f32_head if f32_head else None,
+           "kernels": [{"kernel": e["kernel"] + (" (bf16x6)" if e["kernel"].startswith("mlp_") else ""), "avg_ms": e["avg_ms"],
+                        "equivalent_f32_tflops": e.get("tflops")} for e in t["kernels"]],
+           "final_stats": t["stats"],
+           "note": "opt-in, float32-accurate: x = x1 + x2 + x3 exactly (bf16 each), the six products of order <= 2^-16 on "
+                   "v_mfma_f32_32x32x16_bf16, leading product and corrections in separate float32 accumulators; per GEMM at least "
+                   "as close to float64 as the float32-MFMA kernels and held to every bound of the float32 path "
+                   "(tests/test_gpu_x6.py, test_gpu_fullsize.py, test_gpu_trained_state.py, test_gpu_reference_fixtures.py); "
+                   "`equivalent_f32_tflops` = the float32 path's algorithmic FLOP over this kernel's time (NOT a bf16 rate)"}
+    return rec
 
 
 def split_precision_twin(tr):
@@ -628,6 +682,8 @@ def main(argv=None):
         extras["grid512"] = run_grid(job, tr)
     if "octree" in want and job.cuda:
         extras["octree"] = run_octree(job, a)
+    if "bf16x6" in want and job.cuda:
+        extras["opt_in_bf16x6_training"] = run_x6(job, a, tr["per_gpu"] * world * a.steps / tr["elapsed"])
     if "bf16x3" in want:
         # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
         twin = split_precision_twin(tr)

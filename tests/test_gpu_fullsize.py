@@ -36,6 +36,16 @@ PRESETS = {
 }
 B_FULL = 4096
 GRAD_BOUND = {4096: 2e-3, 512: 4e-3}
+# Every HIP leg runs in native float32 AND in its opt-in float32-accurate emulation on the bf16 matrix pipe
+# (PxoCfg.mlp_precision = bf16x6, csrc/mlp_x6_kernels.hip) -- at the SAME bounds.  The oracle legs are computed once per case.
+PRECISIONS = [("f32", 0), ("bf16x6", 2)]
+_ORACLE = {}
+
+
+def _once(key, fn):
+    if key not in _ORACLE:
+        _ORACLE[key] = fn()
+    return _ORACLE[key]
 
 
 def _threads():
@@ -56,11 +66,13 @@ def _record(name, **kv):
             f.write('{"test": "%s", %s}\n' % (name, ", ".join('"%s": %.6g' % (k, v) for k, v in kv.items())))
 
 
+@pytest.mark.parametrize("prec_name,prec", PRECISIONS)
 @pytest.mark.parametrize("preset,randomized", [("blender", True), ("blender", False), ("tt", True)])
-def test_render_fwd_full_batch(preset, randomized):
+def test_render_fwd_full_batch(preset, randomized, prec_name, prec):
     """pxo_render_fwd on 4096 rays against O.render (NerfModel.__call__, nerf_sh/nerf/models.py:216-348)."""
     ops = _ops(); dev = _gpu(); _threads()
     cfg = O.Cfg(**PRESETS[preset]); pcfg = pxo_cfg(ops, cfg)
+    pcfg.mlp_precision = prec
     flat = make_params(cfg, bias_scale=0.2)
     B = B_FULL
     rays = _rays_for(preset, B, 141)
@@ -72,8 +84,8 @@ def test_render_fwd_full_batch(preset, randomized):
                          randomized=randomized, t_rand=None if t_rand is None else t_rand.to(dev),
                          u=None if u is None else u.to(dev))
     t0 = time.time()
-    ref = oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float32)
-    ref64 = oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float64)
+    ref, ref64 = _once(("render", preset, randomized), lambda: (oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float32),
+                                                                 oracle_render_chunked(flat, rays, cfg, t_rand, u, torch.float64)))
     t_cpu = time.time() - t0
     for lvl, tag in ((0, "coarse"), (1, "fine")):
         for j, name in ((0, "rgb"), (2, "acc")):
@@ -86,7 +98,7 @@ def test_render_fwd_full_batch(preset, randomized):
     target = torch.rand(B, 3, generator=gen)
     p_hip, p32, p64 = _psnr(out[1][0].cpu(), target), _psnr(ref[1][0], target), _psnr(ref64[1][0], target)
     p_hip_c, p64_c = _psnr(out[0][0].cpu(), target), _psnr(ref64[0][0], target)
-    _record(f"render_fwd[{preset},{randomized}]", psnr_hip=p_hip, psnr_f32=p32, psnr_f64=p64,
+    _record(f"render_fwd[{preset},{randomized},{prec_name}]", psnr_hip=p_hip, psnr_f32=p32, psnr_f64=p64,
             d_f32=abs(p_hip - p32), d_f64=abs(p_hip - p64), oracle_s=t_cpu)
     assert abs(p_hip - p32) <= 1e-4 and abs(p_hip - p64) <= 1e-4, (p_hip, p32, p64)
     assert abs(p_hip_c - p64_c) <= 1e-4
@@ -99,7 +111,7 @@ def test_render_fwd_full_batch(preset, randomized):
     # the far end of the plateau; sample_pdf_kernel now accumulates the cdf in float64 (93.4 dB, profiles/r03_render_outliers.md).
     err = (out[1][0].cpu().double() - ref64[1][0]).abs().max(dim=-1)[0]
     p_img_hip, p_img_cpu = _psnr(out[1][0].cpu(), ref64[1][0]), _psnr(ref[1][0], ref64[1][0])
-    _record(f"render_fwd_image[{preset},{randomized}]", psnr_hip_vs_f64=p_img_hip, psnr_f32_vs_f64=p_img_cpu,
+    _record(f"render_fwd_image[{preset},{randomized},{prec_name}]", psnr_hip_vs_f64=p_img_hip, psnr_f32_vs_f64=p_img_cpu,
             max_err=float(err.max()), n_over_1e4=float((err > 1e-4).sum()), n_over_1e3=float((err > 1e-3).sum()),
             median_err=float(err.median()))
     assert p_img_hip >= p_img_cpu - (6.0 if randomized else 3.0), (p_img_hip, p_img_cpu)
@@ -107,12 +119,14 @@ def test_render_fwd_full_batch(preset, randomized):
     assert float(err.max()) <= 1e-2 and int((err > 1e-3).sum()) <= 8, (float(err.max()), int((err > 1e-3).sum()))
 
 
+@pytest.mark.parametrize("prec_name,prec", PRECISIONS)
 @pytest.mark.parametrize("preset,wd", [("blender", 0.0), ("tt", 0.0), ("blender", 0.1)])
-def test_train_fwd_bwd_full_batch(preset, wd):
+def test_train_fwd_bwd_full_batch(preset, wd, prec_name, prec):
     """pxo_train_fwd_bwd on one full step (4096 rays + 10k sparsity points) against loss_fn + value_and_grad
     (nerf_sh/train.py:68-116); wd > 0 exercises the weight_decay_mult term of the loss (train.py:101-114)."""
     ops = _ops(); dev = _gpu(); _threads()
     cfg = O.Cfg(weight_decay_mult=wd, **PRESETS[preset]); pcfg = pxo_cfg(ops, cfg)
+    pcfg.mlp_precision = prec
     assert cfg.sparsity_npoints == 10000 and cfg.sparsity_weight == 1e-3
     flat = make_params(cfg, bias_scale=0.2)
     B = B_FULL if wd == 0.0 else 512
@@ -129,8 +143,9 @@ def test_train_fwd_bwd_full_batch(preset, wd):
                       px.to(dev), grads, stats, ws, randomized=True, t_rand=t_rand.to(dev), u=u.to(dev),
                       sp_points=sp_pts.to(dev))
     t0 = time.time()
-    st32, g32 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float32)
-    st64, g64 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float64)
+    (st32, g32), (st64, g64) = _once(("train", preset, wd), lambda: (
+        oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float32),
+        oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float64)))
     t_cpu = time.time() - t0
     s = stats.cpu()
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
@@ -146,21 +161,24 @@ def test_train_fwd_bwd_full_batch(preset, wd):
         e_cpu = float((g32[lo:hi].double() - ref).norm() / ref.norm())
         rec[f"mlp{mi}_hip"] = e_hip; rec[f"mlp{mi}_cpu"] = e_cpu
         assert e_hip <= GRAD_BOUND[B], f"MLP_{mi}: rel L2 err vs f64 oracle {e_hip:.3g} (CPU f32: {e_cpu:.3g})"
-    _record(f"train_fwd_bwd[{preset},wd={wd}]", oracle_s=t_cpu, **rec)
+    _record(f"train_fwd_bwd[{preset},wd={wd},{prec_name}]", oracle_s=t_cpu, **rec)
     if wd > 0:      # the decay term alone: gradient difference between wd and 0 is 2*wd*p/n_params
         grads0 = torch.full_like(fd, float("nan"))
         cfg0 = O.Cfg(**PRESETS[preset])
-        ops.train_fwd_bwd(pxo_cfg(ops, cfg0), fd, packed, rays.origins.to(dev), rays.directions.to(dev),
+        pcfg0 = pxo_cfg(ops, cfg0); pcfg0.mlp_precision = prec
+        ops.train_fwd_bwd(pcfg0, fd, packed, rays.origins.to(dev), rays.directions.to(dev),
                           rays.viewdirs.to(dev), px.to(dev), grads0, stats, ws, randomized=True, t_rand=t_rand.to(dev),
                           u=u.to(dev), sp_points=sp_pts.to(dev))
         close("weight decay term", grads - grads0, 2 * wd * fd / fd.numel(), rtol=1e-3, atol=1e-9)
 
 
-def test_grid_sigma_512_sample():
+@pytest.mark.parametrize("prec_name,prec", PRECISIONS)
+def test_grid_sigma_512_sample(prec_name, prec):
     """pxo_grid_sigma at reso 512 (134,217,728 voxels; octree/extraction.py:290-320) against O.eval_points_raw on
     2^20 randomly chosen voxels whose coordinates follow the reference's grid formula (:294-303)."""
     ops = _ops(); dev = _gpu(); _threads()
     cfg = O.Cfg(); pcfg = pxo_cfg(ops, cfg)
+    pcfg.mlp_precision = prec
     flat = make_params(cfg, bias_scale=0.2)
     pf, _ = ops.pack_weights(pcfg, split_mlp(flat, cfg, 1).to(dev), need_bwd=False)
     reso = 512

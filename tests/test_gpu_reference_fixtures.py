@@ -226,9 +226,13 @@ def test_gaussian_noise_against_reference(golden_dir):
         _allclose("deterministic render ignores noise_std", det[1][0], g["rgb_fine_r0"], 0, 2e-5)
 
 
-def _train_once(ops, dev, g, gw, shift, n_sp, wd):
+PRECISIONS = [("f32", 0), ("bf16x6", 2)]     # native float32 and its opt-in float32-accurate emulation (csrc/mlp_x6_kernels.hip)
+
+
+def _train_once(ops, dev, g, gw, shift, n_sp, wd, prec=0):
     cfg = O.Cfg(sparsity_npoints=n_sp, weight_decay_mult=wd)
     pcfg = pxo_cfg(ops, cfg)
+    pcfg.mlp_precision = prec
     flat = _params_flat(gw, shift).to(dev)
     n = flat.numel() // 2
     packed = [ops.pack_weights(pcfg, flat[i * n:(i + 1) * n].contiguous()) for i in range(2)]
@@ -243,20 +247,22 @@ def _train_once(ops, dev, g, gw, shift, n_sp, wd):
     return cfg, dict(zip(utils.Stats._fields, stats.cpu().tolist())), grads.cpu()
 
 
-def test_train_stats_against_reference_loss_fn(golden_dir):
+@pytest.mark.parametrize("prec_name,prec", PRECISIONS)
+def test_train_stats_against_reference_loss_fn(golden_dir, prec_name, prec):
     """L1.  train_loss.npz: Stats of the reference's own train_step (500 sparsity points, weight_decay_mult 0.1).
     loss / loss_c / weight_l2 / psnr / psnr_c rel 2e-5; loss_sp rel 5e-3 (it is 1e-3 * (1 - mean exp(-0.05 relu sigma)):
     a difference of nearly equal numbers)."""
     ops = _ops(); dev = _gpu()
     g = np.load(os.path.join(golden_dir, "train_loss.npz"))
     gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
-    _, st, _ = _train_once(ops, dev, g, gw, 0.0, int(g["sparsity_npoints"]), float(g["weight_decay_mult"]))
+    _, st, _ = _train_once(ops, dev, g, gw, 0.0, int(g["sparsity_npoints"]), float(g["weight_decay_mult"]), prec)
     for k in ("loss", "loss_c", "weight_l2", "psnr", "psnr_c"):
         assert st[k] == pytest.approx(float(g[k]), rel=2e-5), (k, st[k], float(g[k]))
     assert st["loss_sp"] == pytest.approx(float(g["loss_sp"]), rel=5e-3, abs=1e-9)
 
 
-def test_train_gradient_against_reference_autograd(golden_dir):
+@pytest.mark.parametrize("prec_name,prec", PRECISIONS)
+def test_train_gradient_against_reference_autograd(golden_dir, prec_name, prec):
     """G1.  train_grad.npz: float64 reverse-mode AD through the reference's loss_fn body (make_golden_grad.py), 24 rays,
     500 sparsity points, weight decay on.  A 24-ray step in float32 is noisy (a pre-activation within round-off of 0 takes
     either ReLU branch; the fine positions come from a float32 inverse CDF with a condition number of ~1e4): the REFERENCE'S
@@ -269,14 +275,14 @@ def test_train_gradient_against_reference_autograd(golden_dir):
     g = np.load(os.path.join(golden_dir, "train_grad.npz"))
     gw = np.load(os.path.join(golden_dir, "eval_points_sh16.npz"))
     cfg, st, grad = _train_once(ops, dev, g, gw, float(g["sigma_bias_shift"]), int(g["sparsity_npoints"]),
-                                float(g["weight_decay_mult"]))
+                                float(g["weight_decay_mult"]), prec)
     want = torch.tensor(g["grad"]).double()
     got = grad.double()
     n = want.numel() // 2
     ref32 = (float(g["grad_f32_vs_f64_rel_l2_mlp0"]), float(g["grad_f32_vs_f64_rel_l2_mlp1"]))
     bounds = (2 * ref32[0], 2 * ref32[1])
     rels = [float((got[i * n:(i + 1) * n] - want[i * n:(i + 1) * n]).norm() / want[i * n:(i + 1) * n].norm()) for i in range(2)]
-    print(f"HIP vs reference-autograd gradient: MLP_0 rel L2 {rels[0]:.2e}, MLP_1 {rels[1]:.2e} "
+    print(f"HIP ({prec_name}) vs reference-autograd gradient: MLP_0 rel L2 {rels[0]:.2e}, MLP_1 {rels[1]:.2e} "
           f"(the reference's own float32 evaluation: {ref32[0]:.2e} / {ref32[1]:.2e})")
     assert rels[0] <= bounds[0] and rels[1] <= bounds[1], rels
     off = 0

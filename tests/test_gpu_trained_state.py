@@ -74,13 +74,21 @@ def trained():
     return dict(args=args, model=model, state=state, ds=ds, dev=dev)
 
 
-def test_trained_step_matches_f64_oracle(trained):
+_ORACLE = {}
+
+
+@pytest.mark.parametrize("prec_name,prec", [("f32", 0), ("bf16x6", 2)])
+def test_trained_step_matches_f64_oracle(trained, prec_name, prec):
+    """HIP legs in native float32 and in the opt-in bf16x6 emulation (csrc/mlp_x6_kernels.hip), same batch (the fixture's
+    sampler is re-seeded per leg through the module-level cache of the batch), same bounds."""
     ops = _ops(); dev = trained["dev"]
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     args, state = trained["args"], trained["state"]
     cfg = O.Cfg()                       # blender preset = the oracle's defaults (asserted below)
     assert (cfg.sh_deg, cfg.near, cfg.far, cfg.sparsity_npoints) == (args.sh_deg, args.near, args.far, args.sparsity_npoints)
-    batch = next(trained["ds"])          # 4,096 random pixels of one training image
+    if "batch" not in _ORACLE:
+        _ORACLE["batch"] = next(trained["ds"])          # 4,096 random pixels of one training image (one batch for both legs)
+    batch = _ORACLE["batch"]
     rays_dev = batch["rays"]; px_dev = batch["pixels"]
     gen = torch.Generator().manual_seed(20200823)
     t_rand = torch.rand(RAYS, 64, generator=gen); u = torch.rand(RAYS, 128, generator=gen)
@@ -91,6 +99,7 @@ def test_trained_step_matches_f64_oracle(trained):
     for skip in (0, 1):
         pcfg = type(trained["model"].cfg).from_buffer_copy(trained["model"].cfg)      # PxoCfg is a ctypes struct
         pcfg.skip_zero_rows = skip
+        pcfg.mlp_precision = prec
         packed = [ops.pack_weights(pcfg, fd[i * n:(i + 1) * n].contiguous()) for i in range(2)]
         grads = torch.full_like(fd, float("nan")); stats = torch.zeros(6, device=dev)
         ws = torch.empty(ops.train_workspace_bytes(pcfg, RAYS), dtype=torch.uint8, device=dev)
@@ -108,8 +117,10 @@ def test_trained_step_matches_f64_oracle(trained):
     flat = fd.cpu()
     rays = O.Rays(*[r.cpu() for r in rays_dev]); px = px_dev.cpu()
     tc = time.time()
-    st32, g32 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float32)
-    st64, g64 = oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float64)
+    if "oracle" not in _ORACLE:
+        _ORACLE["oracle"] = (oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float32),
+                             oracle_loss_and_grad_chunked(flat, rays, px, cfg, t_rand, u, sp_pts, torch.float64))
+    (st32, g32), (st64, g64) = _ORACLE["oracle"]
     t_cpu = time.time() - tc
     rec = dict(live_chunk_fraction=l1 / t1_, oracle_s=t_cpu, psnr_batch_f64=st64["psnr"], psnr_batch_f32=st32["psnr"],
                psnr_batch_hip=float(s0[1]))
@@ -125,7 +136,7 @@ def test_trained_step_matches_f64_oracle(trained):
         e_cpu = float((g32[lo:hi].double() - ref).norm() / ref.norm())
         rec[f"mlp{mi}_hip"] = e_hip; rec[f"mlp{mi}_f32_oracle"] = e_cpu; rec[f"mlp{mi}_grad_norm"] = float(ref.norm())
         errs.append((mi, e_hip, e_cpu))
-    _record("trained_step", **rec)
+    _record(f"trained_step[{prec_name}]", **rec)
     print("trained step:", json.dumps(rec))
     for i, k in enumerate(("loss", "psnr", "loss_c", "loss_sp", "psnr_c", "weight_l2")):
         rtol = 5e-3 if k == "loss_sp" else 2e-5
@@ -136,7 +147,8 @@ def test_trained_step_matches_f64_oracle(trained):
         assert e_hip <= bound, f"MLP_{mi}: rel L2 err vs f64 oracle {e_hip:.3g} > {bound:.3g} (CPU f32 oracle: {e_cpu:.3g})"
 
 
-def test_trained_render_matches_f64_oracle(trained):
+@pytest.mark.parametrize("prec_name,prec", [("f32", 0), ("bf16x6", 2)])
+def test_trained_render_matches_f64_oracle(trained, prec_name, prec):
     """render_image's per-chunk call (pxo_render_fwd, deterministic sampling as nerf_sh/eval.py:57) on every 4th pixel in
     both axes of one held-out 800 x 800 view (40,000 rays) at the trained weights, against the float64 oracle's render of
     the same weights; PSNRs are taken against the view's ground truth as nerf_sh/train.py:245-268 does."""
@@ -144,6 +156,10 @@ def test_trained_render_matches_f64_oracle(trained):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     from plenoctree_amd.nerf_sh.nerf import datasets, utils
     model, state = trained["model"], trained["state"]
+    if prec:        # the same weights through the opt-in bf16x6 kernels (their own weight images)
+        from plenoctree_amd.nerf_sh.nerf import models
+        cfg6 = type(model.cfg).from_buffer_copy(model.cfg); cfg6.mlp_precision = prec
+        model, state = models.NerfModel(cfg6), models.TrainState(cfg6, state.params.clone())
     test = datasets.Synthetic("test", trained["args"], dev)
     ex = test.get_image(67)
     sub = lambda t: t[::4, ::4].reshape(-1, 3).contiguous()
@@ -157,7 +173,9 @@ def test_trained_render_matches_f64_oracle(trained):
     cfg = O.Cfg()
     rays = O.Rays(*[r.cpu() for r in rays_dev])
     tc = time.time()
-    ref64 = oracle_render_chunked(state.params.cpu(), rays, cfg, None, None, torch.float64, chunk=2048)
+    if "render64" not in _ORACLE:
+        _ORACLE["render64"] = oracle_render_chunked(state.params.cpu(), rays, cfg, None, None, torch.float64, chunk=2048)
+    ref64 = _ORACLE["render64"]
     t_cpu = time.time() - tc
     p_hip, p64 = _psnr(rgb_hip[1], px), _psnr(ref64[1][0], px)
     p_hip_c, p64_c = _psnr(rgb_hip[0], px), _psnr(ref64[0][0], px)
@@ -167,7 +185,7 @@ def test_trained_render_matches_f64_oracle(trained):
                max_err=float(err.max()), n_over_1e3=int((err > 1e-3).sum()), median_err=float(err.median()),
                acc_max_err=float((acc_hip.double() - ref64[1][2]).abs().max()),
                background_fraction=float((ref64[1][2] < 1e-3).double().mean()), oracle_s=t_cpu)
-    _record("trained_render", **rec)
+    _record(f"trained_render[{prec_name}]", **rec)
     print("trained render:", json.dumps(rec))
     assert p64 > 22.0, p64                                   # the trained regime, not the 14 dB one
     assert abs(p_hip - p64) <= 1e-4, (p_hip, p64)

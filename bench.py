@@ -61,9 +61,10 @@ def parse(argv=None):
                         "multi-GPU code path on a 1-GPU box)")
     p.add_argument("--no-kernel-events", action="store_true",
                    help="A/B only: no HIP events around the dominant kernels in the timed region (no roofline leg)")
-    p.add_argument("--per-host-image", action="store_true",
-                   help="batches as the reference draws them on ONE host: one image per step, its pixels sharded over the ranks "
-                        "(datasets shard=(rank, world)); default: every rank its own image (the reference's multi-host sampler)")
+    p.add_argument("--per-host-image", choices=["auto", "true", "false"], default="auto", nargs="?", const="true",
+                   help="true: batches as the reference draws them on ONE host -- one image per step, its pixels sharded over the "
+                        "ranks (datasets shard=(rank, world)); false: every rank its own image (the reference's multi-host "
+                        "sampler); auto (default): true when all ranks share one host")
     p.add_argument("--tune", default="", help="A/B only: pxo_set_tuning knobs, e.g. tile_sched=1,wgrad_ranges=73,wgrad_skinny_ranges=128 "
                                               "(same results, different schedule; recorded in the line as `tuning`)")
     p.add_argument("--cpu-rays", type=int, default=1024, help="rays per step of the CPU baseline (BASELINE.md section 3: 1024)")
@@ -317,7 +318,7 @@ def run_train(job, preset, steps, warmup, per_gpu=None, snapshot_step=None, even
     args = flags_for(a, preset, per_gpu, **flag_over)
     model, params = models.construct_nerf(args, job.device)
     state = models.TrainState(model.cfg, params)
-    if a.per_host_image:
+    if job.pdist.per_host_image(a.per_host_image, job.world):
         dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473, shard=(job.rank, job.world))
     else:
         dataset = datasets.Synthetic("train", args, job.device, batch_size=per_gpu, seed=20201473 + job.rank)
@@ -744,6 +745,10 @@ def main(argv=None):
                                    "800x800 synthetic views, sparsity 10k pts, Adam",
                        "rays_per_gpu": per_gpu, "global_batch": per_gpu * world, "sh_deg": deg,
                        "parallelism": f"dp{world}"},
+            "batch_sampler": ("one image per step, its pixels sharded over the ranks (the reference on one host: datasets.py:159-166 + "
+                              "utils.shard)" if job.pdist.per_host_image(a.per_host_image, world) else
+                              "every rank its own image per step (the reference's multi-host sampler, train.py:128)") if world > 1 else
+                             "one image per step (datasets.py:159-166)",
             "nccl_ranks_seen": job.ranks_seen if (job.exchange or world > 1) else 1, "collectives_per_step": head["collectives_per_step"],
             "step_mfma_frac": value / world * FLOP_TRAIN_PER_RAY[deg] / (PEAK_F32_MFMA_TFLOPS * 1e12),
             "final_stats": head["stats"],

@@ -171,6 +171,35 @@ def init_from_env(backend=None, device=None):
     return Comm(world, rank, local_rank, backend)
 
 
+def single_host(world=None):
+    """Do all ranks of this job sit on ONE host?  torch.distributed.run exports LOCAL_WORLD_SIZE (ranks on this node): equal to
+    WORLD_SIZE on one node.  Without a launcher (mp.spawn in tests) a loopback MASTER_ADDR says the same."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if world <= 1:
+        return True
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    if lws is not None:
+        return int(lws) == world
+    return os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1")
+
+
+def per_host_image(flag, world=None):
+    """Resolve --per_host_image (true / false / auto).  auto = what the reference does on the machine at hand: ranks that share
+    a host are its `jax.local_devices()` -- ONE image per step, its batch_size pixels drawn once and sharded over them
+    (nerf_sh/nerf/datasets.py:159-166 + nerf_sh/nerf/utils.py:518-522); ranks on different hosts each draw their own image
+    (np.random.seed(20201473 + jax.host_id()), nerf_sh/train.py:128).  Hybrid layouts (several hosts x several ranks) keep the
+    multi-host sampler unless the flag says otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if isinstance(flag, str):
+        f = flag.lower()
+        if f in ("auto", ""):
+            return world > 1 and single_host(world)
+        return f in ("1", "true", "yes", "y")
+    if flag is None:
+        return world > 1 and single_host(world)
+    return bool(flag)
+
+
 def slab_range(reso, world, rank):
     """x-slab [x0,x1) of a reso^3 grid owned by `rank` (contiguous, sizes differ by at most 1)."""
     base, rem = divmod(reso, world)

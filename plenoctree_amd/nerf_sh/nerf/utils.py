@@ -18,6 +18,14 @@ def namedtuple_map(fn, tup):
     return type(tup)(*map(fn, tup))
 
 
+def _tristate(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() == "auto":
+        return "auto"
+    return _bool(v)
+
+
 def _bool(v):
     if isinstance(v, bool):
         return v
@@ -56,7 +64,9 @@ def define_flags(parser=None):
     # not a reference flag: with N ranks on one node, sample like the reference on ONE host with N local devices -- one image
     # per step, its batch_size pixels drawn once and sharded over the ranks (datasets.py:159-166 + utils.shard) -- instead of
     # like N hosts (each rank its own image).  N x (batch_size / N) then replays the 1 x batch_size batches exactly.
-    a("--per_host_image", type=_bool, default=False)
+    # Default auto: ranks that share ONE host sample like the reference's local devices (true); ranks on different hosts like
+    # its hosts (false).  dist.per_host_image() resolves it.
+    a("--per_host_image", type=_tristate, default="auto")
     a("--skip_layer", type=int, default=4)
     a("--num_rgb_channels", type=int, default=3)
     a("--num_sigma_channels", type=int, default=1)

@@ -40,6 +40,7 @@ def main(argv=None):
     write_ts_now(0)
 
     per_rank = args.batch_size // comm.world
+    args.per_host_image = dist.per_host_image(args.per_host_image, comm.world)
     if args.per_host_image and not args.image_batching:
         # the reference on ONE host with N local devices: one image per step, its batch_size pixels drawn once and sharded
         # (datasets.py:159-166, utils.py:518-522); every rank carries host 0's seed and takes its contiguous piece of the draw

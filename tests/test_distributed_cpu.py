@@ -195,7 +195,7 @@ def test_slab_range_partitions_grid():
 
 
 def _per_host_worker(rank, world, port, outdir):
-    """`--per_host_image` on gloo ranks: the rank's dataset is a shard of host 0's draw; the shards, gathered in rank order
+    """`--per_host_image` (default auto = true for ranks sharing a host) on gloo ranks: the rank's dataset is a shard of host 0's draw; the shards, gathered in rank order
     with the collective render_image / the reducer use, must be the single-process batch."""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -206,10 +206,16 @@ def _per_host_worker(rank, world, port, outdir):
     from plenoctree_amd.nerf_sh.nerf import datasets, utils
     datasets.Dataset.feeder_factory = staticmethod(feeder_for)
     comm = dist.init_from_env(backend="gloo")
-    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x", "--per_host_image", "true"])
+    # the DEFAULT flags: `--per_host_image auto` resolves to the reference's single-host sampler because the ranks share a host
+    args = utils.define_flags().parse_args(["--config", "synthetic", "--train_dir", "x"])
     utils.update_flags(args); args.factor = 16
-    assert args.per_host_image is True
+    assert args.per_host_image == "auto" and dist.per_host_image(args.per_host_image, comm.world) is True
+    assert dist.per_host_image("false", comm.world) is False and dist.per_host_image("auto", 1) is False
+    os.environ["LOCAL_WORLD_SIZE"] = str(world // 2)          # a launcher that says: two hosts -> the multi-host sampler
+    assert dist.per_host_image("auto", comm.world) is False and dist.per_host_image("true", comm.world) is True
+    del os.environ["LOCAL_WORLD_SIZE"]
     per = 64 // world
+    # (what nerf_sh/train.py builds for per_host_image = true)
     ds = datasets.get_dataset("train", args, torch.device("cpu"), batch_size=per, seed=20201473, shard=(comm.rank, comm.world))
     out = []
     for _ in range(3):

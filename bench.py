@@ -70,7 +70,11 @@ def parse(argv=None):
     p.add_argument("--cpu-rays", type=int, default=1024, help="rays per step of the CPU baseline (BASELINE.md section 3: 1024)")
     p.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the CPU baseline (after --cpu-warmup)")
     p.add_argument("--cpu-warmup", type=int, default=3)
-    p.add_argument("--cpu-full", action="store_true", help="CPU baseline also at B = 4096 (configs[1]; ~3 minutes of CPU)")
+    p.add_argument("--no-cpu-full", action="store_true",
+                   help="leave the B = 4096 shape (configs[1], ~3 minutes of CPU) out of the CPU baseline; `value` is then the B = --cpu-rays figure")
+    p.add_argument("--cpu-full", action="store_true", help="(default since round 6; kept for old command lines)")
+    p.add_argument("--cpu-budget-s", type=float, default=600.0,
+                   help="wall-clock cap of the whole CPU baseline: a shape that would exceed it stops early and reports timed_steps < requested")
     p.add_argument("--converge-steps", type=int, default=2000, help="training budget of the `converge` record")
     p.add_argument("--converge-views", type=int, default=2, help="held-out 800x800 views rendered for eval PSNR")
     # sizes of the other records; the defaults are the BASELINE configs, the dry run passes small ones
@@ -127,10 +131,12 @@ def flags_for(a, preset, batch, **over):
 def cpu_baseline(a, args_ns, device):
     """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores by BASELINE.md section 3's protocol:
     3 warm-up + 10 timed train steps (forward + backward + Adam, float32), rays/s = B x steps/s (nerf_sh/train.py:224), at
-    configs[0]'s shapes -- B = 1024 with 64 coarse samples only and with 64 + 128 samples (+ 10k sparsity points) -- and, with
-    --cpu-full, configs[1]'s B = 4096 (3 minutes of CPU; left out of the default run, which must stay within a few minutes).
-    `value` is the 64 + 128 figure.  Thread count: torch's intra-op pool oversubscribes badly on many-core hosts, so a 32-ray
-    probe picks among a few candidates; the count actually used is reported next to nproc."""
+    configs[0]'s shapes -- B = 1024 with 64 coarse samples only and with 64 + 128 samples (+ 10k sparsity points) -- and at
+    configs[1]'s B = 4096 (the headline's shape, ~3 minutes of CPU; --no-cpu-full leaves it out).  `value` is the B = 4096,
+    64 + 128 figure (the B = 1024 one without it).  Thread count: torch's intra-op pool oversubscribes badly on many-core
+    hosts, so a 32-ray probe picks among a few candidates; BASELINE.md section 3 says `nproc`, so the 64 + 128 shape at B = 1024
+    is ALSO timed with every hardware thread (1 warm-up + 3 timed steps) and reported next to the probed-best figure.  The whole
+    leg is capped at --cpu-budget-s: a shape that runs out of budget stops early and says so (timed_steps < requested)."""
     import platform
     from oracle import nerf_oracle as O
     from plenoctree_amd.nerf_sh.nerf import datasets
@@ -161,6 +167,9 @@ def cpu_baseline(a, args_ns, device):
         out = O.train_step(flat, m, v, step, rays, batch["pixels"], cfg, t_rand, u, sp, 5e-4)
         return out[:3], time.perf_counter() - t0
 
+    if a.cpu_steps < 1 or a.cpu_warmup < 0:
+        raise SystemExit("bench.py: --cpu-steps must be >= 1 and --cpu-warmup >= 0")
+    t_leg = time.perf_counter()
     ncpu = os.cpu_count() or 1
     cfg = cfg_for(True)
     flat = O.flatten_params(O.init_params(cfg))
@@ -175,34 +184,45 @@ def cpu_baseline(a, args_ns, device):
             best, cores = dt, c
     torch.set_num_threads(cores)
 
-    def protocol(n_rays, fine, warm=a.cpu_warmup, timed=a.cpu_steps):
+    def protocol(n_rays, fine, warm=a.cpu_warmup, timed=a.cpu_steps, threads=None):
+        torch.set_num_threads(threads or cores)
         cfg = cfg_for(fine)
         flat = O.flatten_params(O.init_params(cfg))
         m = torch.zeros_like(flat); v = torch.zeros_like(flat)
         ds = host_batches(n_rays)
-        times = []
+        times, last = [], 0.0
         for step in range(warm + timed):
-            (flat, m, v), dt = step_once(cfg, flat, m, v, step, next(ds))
+            # the budget: never start a step that (at the last step's duration) would end past the cap, once one step is timed
+            if times and time.perf_counter() - t_leg + last > a.cpu_budget_s:
+                break
+            (flat, m, v), last = step_once(cfg, flat, m, v, step, next(ds))
             if step >= warm:
-                times.append(dt)
-        return {"rays_per_step": n_rays, "samples": "64+128" if fine else "64", "warmup_steps": warm, "timed_steps": len(times),
+                times.append(last)
+        torch.set_num_threads(cores)
+        if not times:        # out of budget during the warm-up: the last warm-up step is the only measurement there is
+            times = [last]
+        return {"rays_per_step": n_rays, "samples": "64+128" if fine else "64", "threads": threads or cores, "warmup_steps": warm,
+                "timed_steps": len(times), "timed_steps_requested": timed,
                 "rays_per_s": n_rays * len(times) / sum(times), "s_per_step": sum(times) / len(times), "cpu_s": sum(times)}
 
     shapes = [protocol(a.cpu_rays, False), protocol(a.cpu_rays, True)]
     dropped = []
-    if a.cpu_full:
+    if not a.no_cpu_full:
         shapes.append(protocol(4096, True))
     else:
-        dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: run with --cpu-full)")
+        dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: left out by --no-cpu-full)")
+    all_threads = protocol(a.cpu_rays, True, warm=1, timed=3, threads=ncpu) if ncpu != cores else dict(shapes[1])
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    head = shapes[1]
+    head = shapes[-1] if not a.no_cpu_full else shapes[1]
     return {"value": head["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "nproc": ncpu, "cpu_model": cpu_model or platform.processor(), "torch_version": torch.__version__,
+            "nproc": ncpu, "nproc_threads": {"rays_per_s": all_threads["rays_per_s"], "threads": ncpu, "rays_per_step": all_threads["rays_per_step"],
+                                             "timed_steps": all_threads["timed_steps"],
+                                             "note": "BASELINE.md section 3 says nproc threads: the same 64+128 shape with every hardware thread"}, "cpu_model": cpu_model or platform.processor(), "torch_version": torch.__version__,
             "threads_probed": cores, "protocol": f"BASELINE.md section 3: {a.cpu_warmup} warm-up + {a.cpu_steps} timed train steps, rays/s = B x steps/s",
             "shapes": shapes, "shapes_dropped": dropped,
             "sample": f"{head['timed_steps']} timed train steps (after {head['warmup_steps']} warm-up) of {head['rays_per_step']} rays x "

@@ -442,15 +442,8 @@ __global__ __launch_bounds__(kRayThreads) void sample_pdf_kernel(
   __syncthreads();
   if (lane == 0) {  // sequential cumsum keeps the cdf monotone (model_utils.py:248-257)
     cdf[0] = 0.f;
-#ifdef PXO_EXPERIMENT_CDF_F32
-    // A/B builds only (plenoctree_amd/build.py suffix / extra_flags; never the shipped library): the reference's float32
-    // running sum, to measure what the float64 accumulation above changes over a training run (profiles/EXPERIMENTS.md, round 5)
-    float runf = 0.f;
-    for (int i = 0; i + 1 < nw; ++i) { runf += (float)pdf[i]; cdf[i + 1] = fminf(1.f, runf); }
-#else
     double run = 0.0;
     for (int i = 0; i + 1 < nw; ++i) { run += pdf[i]; cdf[i + 1] = (float)fmin(1.0, run); }
-#endif
     cdf[nw] = 1.f;
   }
   __syncthreads();

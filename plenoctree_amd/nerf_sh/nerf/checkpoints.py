@@ -187,16 +187,26 @@ def latest_torch_checkpoint(train_dir):
     return paths[-1] if paths else None
 
 
-def restore_torch_checkpoint(train_dir, state):
+def restore_torch_checkpoint(train_dir, state, trust_pickle=False):
     """restore_model_state (octree/nerf/models.py:52-63): the newest `*.ckpt` of train_dir into `state` (parameters only; a
-    state dict carries no optimizer moments).  Returns the path, or None when there is no such file."""
+    state dict carries no optimizer moments).  Returns the path, or None when there is no such file.  The file is read with
+    weights_only=True; one that also holds non-tensor objects needs trust_pickle=True (the reference's plain torch.load)."""
     path = train_dir if os.path.isfile(train_dir) else latest_torch_checkpoint(train_dir)
     if path is None:
         return None
-    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:            # pickle.UnpicklingError and friends: non-tensor extras (argparse.Namespace, numpy scalars)
+        if not trust_pickle:
+            raise ValueError(
+                f"{path}: holds more than tensors ({type(e).__name__}: {str(e).splitlines()[0][:200]}).  The reference loads its "
+                "*.ckpt files with a plain torch.load, i.e. it unpickles arbitrary objects; this loader does that only when "
+                "asked to: restore_torch_checkpoint(..., trust_pickle=True) / --trust_ckpt_pickle true, for files you trust") from e
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if not isinstance(ckpt, dict) or "model" not in ckpt:
         raise ValueError(f'{path}: not a checkpoint of the reference\'s torch twin (no "model" state dict)')
-    params = torch_state_dict_to_tree(ckpt["model"])
+    from ... import _lib
+    params = torch_state_dict_to_tree(ckpt["model"], depth=_lib.NET_DEPTH)      # the depth the kernels (and state.cfg's arena) are built for
     state.params.copy_(torch.from_numpy(tree_to_arena(params, state.cfg)).to(state.params.device))
     state.m.zero_(); state.v.zero_()
     state.repack()

@@ -228,6 +228,9 @@ def define_flags():
     a("--z_min", type=float, default=None)                   # :91-100: keep only grid points with z_min <= z <= z_max
     a("--z_max", type=float, default=None)
     a("--is_jaxnerf_ckpt", type=utils._bool, nargs="?", const=True, default=False)   # :117-121; see main()
+    # not a reference flag: a `*.ckpt` holding more than tensors (argparse.Namespace, numpy scalars ...) is unpickled in full, like
+    # the reference's plain torch.load, only when this says so (the default reads tensors only and explains itself otherwise)
+    a("--trust_ckpt_pickle", type=utils._bool, nargs="?", const=True, default=False)
     a("--projection_samples", type=int, default=10000)       # :133-137: SH projection of a view-dependent NeRF only
     a("--renderer_step_size", type=float, default=1e-4)
     a("--no_early_stop", action="store_true")
@@ -247,7 +250,7 @@ def load_nerf_checkpoint(args, state):
         if path is None:
             raise FileNotFoundError(f"--is_jaxnerf_ckpt: no flax checkpoint_<step> in {args.train_dir}")
         return f"* restore ckpt from {path} (flax msgpack)"
-    path = checkpoints.restore_torch_checkpoint(args.train_dir, state)
+    path = checkpoints.restore_torch_checkpoint(args.train_dir, state, trust_pickle=bool(getattr(args, "trust_ckpt_pickle", False)))
     if path is not None:
         return f"* restore ckpt from {path}. (torch state dict)"
     path = checkpoints.restore_checkpoint(args.train_dir, state)

@@ -1,4 +1,6 @@
 """Shared helpers of the -m gpu parity tests (HIP path through the C ABI vs the CPU oracle)."""
+import os
+
 import numpy as np   # noqa: F401
 import pytest
 import torch
@@ -245,6 +247,32 @@ def twin_short_steps(cfg):
         t_rand = torch.rand(B, 64, generator=g); u = torch.rand(B, 128, generator=g)
         sp = (torch.rand(TWIN_SHORT_SPARSITY, 3, generator=g) * 2 - 1) * 1.5
         yield step, batch, t_rand, u, sp, utils.learning_rate_decay(step, 5e-4, 5e-6, steps)
+
+
+def twin_short_digests(cfg):
+    """What the committed oracle leg of the 64 x 400 twin (tests/golden/trained_twin_64x400.json) depends on, as two sha256
+    digests: the oracle's SOURCE (oracle/nerf_oracle.py) and the INPUTS it was run on (initial parameters, every 50th step's
+    batch / randoms / learning rate, the held-out rays and pixels) as this code generates them today.  The test compares them
+    with the fixture's: a change to the oracle, the seeds, the sampler or the scene makes the fixture stale, and the test then
+    trains the oracle live instead of comparing HIP with an oracle that no longer exists."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "..", "oracle", "nerf_oracle.py"), "rb") as f:
+        code = hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()
+    # values are hashed on a 2^-12 grid: the scene's pixels are float32 torch-CPU arithmetic, whose last bit may differ between
+    # hosts (vector math libraries); a changed seed, sampler or scene moves them by far more
+    q = lambda t: torch.round(t.double() * 4096.0).to(torch.int64).contiguous().numpy().tobytes()
+    h.update(q(O.flatten_params(O.init_params(cfg, seed=20200823))))
+    for step, batch, t_rand, u, sp, lr in twin_short_steps(cfg):
+        if step % 50 == 0 or step == TWIN_SHORT_STEPS - 1:
+            for t in (*batch["rays"], batch["pixels"], t_rand, u, sp):
+                h.update(q(t))
+            h.update(("%.9e" % float(lr)).encode())
+    rays, px = twin_heldout()
+    for t in (*rays, px):
+        h.update(q(t))
+    return {"oracle_sha256": code, "inputs_sha256": h.hexdigest()}
 
 
 def _twin_args():

@@ -42,6 +42,7 @@ def short_run():
                psnr_init=H._psnr(init, px), psnr_trained=H._psnr(trained, px), param_sum=float(p.double().sum()),
                param_abs_sum=float(p.double().abs().sum()), torch_version=torch.__version__, threads=torch.get_num_threads(),
                oracle_s=time.time() - t0)
+    out.update(H.twin_short_digests(cfg))       # what this leg depends on: the test falls back to a live leg when they change
     print(out)
     with open(os.path.join(HERE, f"trained_twin_{H.TWIN_SHORT_RAYS}x{H.TWIN_SHORT_STEPS}.json"), "w") as f:
         json.dump(out, f)

@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 ARGS = ["--backend", "gloo", "--batch", "8", "--steps", "2", "--warmup", "1", "--strong-rays", "4", "--grid-reso", "8",
         "--eval-step", "2", "--converge-steps", "2", "--converge-views", "1", "--image-factor", "100",
-        "--sparsity-npoints", "16", "--cpu-rays", "8", "--cpu-steps", "1", "--cpu-warmup", "1", "--per-host-image",
+        "--sparsity-npoints", "16", "--cpu-rays", "8", "--cpu-steps", "1", "--cpu-warmup", "1", "--no-cpu-full", "--per-host-image",
         "--extras", "converge,strong512,render_fwd,grid512,coarse64,tt_sh25"]
 
 

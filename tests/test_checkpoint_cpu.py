@@ -124,6 +124,16 @@ def test_torch_state_dict_checkpoint_of_the_reference_twin(tmp_path, monkeypatch
     st.m += 1.0
     path = checkpoints.restore_torch_checkpoint(str(tmp_path), st)
     assert os.path.basename(path) == "000100.ckpt" and float(st.m.abs().max()) == 0.0        # sorted()[-1]; no stale moments
+    # a file that also holds non-tensor objects (the reference's plain torch.load would unpickle them): refused with a message
+    # that names the way out, read with trust_pickle=True
+    import argparse
+    extra = tmp_path / "extra"; extra.mkdir()
+    torch.save({"model": model.state_dict(), "args": argparse.Namespace(lr=5e-4)}, str(extra / "000200.ckpt"))
+    with pytest.raises(ValueError, match="trust_pickle=True"):
+        checkpoints.restore_torch_checkpoint(str(extra), st)
+    p0 = st.params.clone()
+    assert checkpoints.restore_torch_checkpoint(str(extra), st, trust_pickle=True).endswith("000200.ckpt")
+    assert torch.equal(st.params, p0)
     pts = (torch.rand(64, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 1.5
     with torch.no_grad():
         rgb, sigma = model.eval_points_raw(pts)

@@ -283,3 +283,17 @@ def test_trained_psnr_twin_long(golden_dir):
     assert abs(mean_hip - psnr_ref) <= 0.1, (mean_hip, psnr_ref, legs)
     assert max(abs(x - psnr_ref) for x in legs) <= 0.15 and max(legs) - min(legs) <= 0.12, (legs, psnr_ref)
     assert abs(psnr_hip - psnr_cross) <= 1e-4, (psnr_hip, psnr_cross)
+    _ORACLE["twin_long"] = (psnr_hip, psnr_ref)
+
+
+@pytest.mark.xfail(reason="KNOWN, kept visible: as a SINGLE pair against the FLOAT32 oracle's run the long twin is 0.11 dB apart "
+                          "(23.93 vs 24.04 dB), above north_star's 0.1 dB.  The bar is met against the float64 oracle (0.03 dB, "
+                          "single pair) and by the mean of four HIP legs (0.08 dB vs float32, 0.002 dB vs float64): "
+                          "test_trained_psnr_twin_long, DESIGN.md section 2.", strict=False)
+def test_trained_psnr_twin_long_single_pair_vs_f32_oracle():
+    """The round-5 advisor's item: the original single-pair criterion stays in the suite as an expected failure, so that the
+    0.11 dB is a number every run prints, not a sentence in a document."""
+    if "twin_long" not in _ORACLE:
+        pytest.skip("test_trained_psnr_twin_long did not run in this session")
+    psnr_hip, psnr_f32_oracle = _ORACLE["twin_long"]
+    assert abs(psnr_hip - psnr_f32_oracle) <= 0.1, (psnr_hip, psnr_f32_oracle)

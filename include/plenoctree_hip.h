@@ -321,7 +321,9 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
                    const float offset[3], const float scale[3], float* sigma_out, void* stream);
 
 /* ---- run-time choices between implementations of the same result ----------------------- */
-/* Process-wide.  The tile schedule leaves every bit unchanged; the split-K ranges change the (still fixed) order of the
+/* Process-wide, and not synchronised with steps in flight on other host threads: a step reads each knob once when it is
+ * enqueued (and records what it decided: pxo_train_backward_work reports for the step that ran, not for today's knobs).
+ * The tile schedule leaves every bit unchanged; the split-K ranges change the (still fixed) order of the
  * weight-gradient sums, i.e. float32 round-off (tests/test_gpu_parity.py holds both).  Used by A/B sessions (bench.py --tune)
  * and equality tests; nothing is read from the environment.
  *   PXO_TUNE_TILE_SCHED    how the persistent workgroups of the dense training kernels (mlp_fwd with saved tensors,

@@ -1,10 +1,13 @@
 // C ABI of the gfx950 NeRF-SH hot path (see include/plenoctree_hip.h).  Host-side glue only:
 // argument checks, workspace carving and the kernel sequences of NerfModel.__call__
 // (nerf_sh/nerf/models.py:216-348) and loss_fn/value_and_grad (nerf_sh/train.py:66-116).
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pxo_common.h"
@@ -46,9 +49,16 @@ int num_cus() {
 // run-time choices between implementations of the same result (pxo_set_tuning)
 // tile schedule: the device counter by default (r05b: 3.548 vs 3.556 ms per step at 512 rays, 23.78 vs 23.84 at 4096 in one
 // process, profiles/r05b_tune_ab.jsonl; and a workgroup that starts late is not the launch's tail, r05b_contention_probe.jsonl)
-static int g_tune_tile_sched = 1;
-static int g_tune_wgrad_ranges = 0;
-static int g_tune_wgrad_skinny_ranges = 0;
+// (atomics: a knob may be set from one host thread while another enqueues a step; each step reads a knob at most once per
+// decision and records what it decided, see g_step_skipped below)
+static std::atomic<int> g_tune_tile_sched{1};
+static std::atomic<int> g_tune_wgrad_ranges{0};
+static std::atomic<int> g_tune_wgrad_skinny_ranges{0};
+// Did the last pxo_train_fwd_bwd* call on a workspace run its reverse pass in skipping mode?  Decided once per step from the
+// cfg AND the split-K tuning in force at that moment; pxo_train_backward_work reports for THAT decision, whatever
+// pxo_set_tuning did since.
+static std::mutex g_step_mu;
+static std::unordered_map<const void*, bool> g_step_skipped;
 int tune_tile_sched() { return g_tune_tile_sched; }
 int tune_wgrad_ranges() { return g_tune_wgrad_ranges; }
 int tune_wgrad_skinny_ranges() { return g_tune_wgrad_skinny_ranges; }
@@ -574,6 +584,10 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   // (a pass whose weight-gradient row ranges would not fit the kernels' live-chunk lists -- > 32,768 rows per range, i.e.
   // more than 8.4 M sample rows on 256 CUs -- makes the whole reverse pass dense: same bits, no saving)
   const bool skip = cfg->skip_zero_rows != 0 && wgrad_skip_supported(t.c.M) && (Nf == 0 || wgrad_skip_supported(t.f.M));
+  {
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    g_step_skipped[ws] = skip;
+  }
   uint8_t* const live_c = skip ? t.c.live : nullptr;
   uint8_t* const live_f = skip ? t.f.live : nullptr;
   PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c,
@@ -621,8 +635,16 @@ int pxo_train_backward_work(const PxoCfg* cfg, int64_t B, void* ws, size_t ws_by
   hipStream_t s = (hipStream_t)stream;
   const int64_t nc = (t.c.M + kLiveRows - 1) / kLiveRows, nf = cfg->num_fine_samples > 0 ? (t.f.M + kLiveRows - 1) / kLiveRows : 0;
   *total_chunks = nc + nf;
-  // dense pass (also when the step fell back to it because a row range would not fit the live lists): every chunk is live
-  if (!cfg->skip_zero_rows || !wgrad_skip_supported(t.c.M) || (nf > 0 && !wgrad_skip_supported(t.f.M))) {
+  // dense pass (also when the step fell back to it because a row range would not fit the live lists): every chunk is live.
+  // The mode is the one the last step on this workspace RECORDED, not one re-derived from today's tuning knobs.
+  bool skipped = false;
+  {
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    auto it = g_step_skipped.find(ws);
+    if (it == g_step_skipped.end()) { set_error("pxo_train_backward_work: no pxo_train_fwd_bwd call has used this workspace"); return PXO_ERR_ARG; }
+    skipped = it->second;
+  }
+  if (!skipped) {
     *live_chunks = nc + nf;
     return PXO_OK;
   }

@@ -49,8 +49,9 @@ def area_resize(image, out_h, out_w):
     return np.einsum("yjc,xj->yxc", rows, wx).astype(np.float32)
 
 
-def analytic_scene_rgb(origins, directions, white_bkgd=True):
-    """Colour seen along each ray: three hard spheres with view-dependent shading."""
+def analytic_scene_rgb(origins, directions, white_bkgd=True, return_alpha=False):
+    """Colour seen along each ray: three hard spheres with view-dependent shading.  return_alpha: also the hit mask (1.0 where a
+    sphere is hit, 0.0 on the background) -- the alpha channel an RGBA export of the scene carries (scripts/export_scene.py)."""
     o, d = origins.double(), directions.double()
     d = d / d.norm(dim=-1, keepdim=True)
     centers = torch.tensor([[0.0, 0.0, 0.0], [0.7, 0.3, 0.2], [-0.5, -0.4, 0.5]], dtype=torch.float64, device=o.device)
@@ -71,6 +72,8 @@ def analytic_scene_rgb(origins, directions, white_bkgd=True):
         col = (b * diffuse[..., None] + 0.3 * spec[..., None]).clamp(0, 1)
         color = torch.where(hit[..., None], col, color)
         best_t = torch.where(hit, t, best_t)
+    if return_alpha:
+        return color.float(), torch.isfinite(best_t).float()
     return color.float()
 
 
@@ -205,10 +208,15 @@ class Synthetic(Dataset):
     construction and kept resident (100 x 800 x 800 x 3 f32 = 0.77 GB on the device); a batch is then one gather."""
 
     def _load(self, args):
-        n = 100 if self.split == "train" else 200
+        # Optional attributes of `args` (not flags; scripts/export_scene.py and the on-disk-format tests set them): synthetic_hw =
+        # (h, w) with the same horizontal field of view, synthetic_views = (n_train, n_test), synthetic_8bit = colours rounded to
+        # k / 255 -- what a PNG of the view holds, so that a run on the exported files and a run on this class see the same bits.
+        n_views = getattr(args, "synthetic_views", None) or (100, 200)
+        n = n_views[0] if self.split == "train" else n_views[1]
         side = 800 if args.factor == 0 else max(800 // args.factor, 8)
-        self.h = self.w = side
+        self.h, self.w = getattr(args, "synthetic_hw", None) or (side, side)
         self.focal = 0.5 * self.w / np.tan(0.5 * 0.6911112)
+        self.quantize8 = bool(getattr(args, "synthetic_8bit", False))
         rs = np.random.RandomState(7 if self.split == "train" else 11)
         self.camtoworlds = np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(n)])
         self.n_examples = n
@@ -219,11 +227,14 @@ class Synthetic(Dataset):
             for i0 in range(0, n, 20):                     # 20 views per evaluation of the analytic scene
                 rays = [self._rays_for(i, ids) for i in range(i0, min(i0 + 20, n))]
                 o = torch.cat([r.origins for r in rays]); d = torch.cat([r.directions for r in rays])
-                chunks.append(analytic_scene_rgb(o, d, self.white_bkgd).reshape(len(rays), self.h * self.w, 3))
+                chunks.append(self._q8(analytic_scene_rgb(o, d, self.white_bkgd)).reshape(len(rays), self.h * self.w, 3))
             self.images = torch.cat(chunks).contiguous()
 
+    def _q8(self, rgb):
+        return (torch.round(rgb * 255.0) / 255.0) if self.quantize8 else rgb
+
     def _render(self, image_index, ray_indices, rays):
-        return analytic_scene_rgb(rays.origins, rays.directions, self.white_bkgd).contiguous()
+        return self._q8(analytic_scene_rgb(rays.origins, rays.directions, self.white_bkgd)).contiguous()
 
     def _pixels_for(self, image_index, ray_indices, rays):
         if self.images is not None:

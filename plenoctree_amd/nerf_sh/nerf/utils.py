@@ -67,6 +67,12 @@ def define_flags(parser=None):
     # Default auto: ranks that share ONE host sample like the reference's local devices (true); ranks on different hosts like
     # its hosts (false).  dist.per_host_image() resolves it.
     a("--per_host_image", type=_tristate, default="auto")
+    # not reference flags: shape of the `synthetic` dataset (the analytic stand-in scene) -- image size with the same horizontal
+    # field of view, number of train / test poses, colours on the 8-bit grid of a PNG.  With them a run on `synthetic` and a run
+    # on the same scene exported to the reference's on-disk formats (scripts/export_scene.py) see the same bits.
+    a("--synthetic_hw", type=int, nargs=2, default=None)
+    a("--synthetic_views", type=int, nargs=2, default=None)
+    a("--synthetic_8bit", type=_bool, default=False)
     a("--skip_layer", type=int, default=4)
     a("--num_rgb_channels", type=int, default=3)
     a("--num_sigma_channels", type=int, default=1)

@@ -12,6 +12,9 @@
 #   octree     tests/test_gpu_octree.py + scripts/octree_bench.py $OBENCH_ARGS               -> gpurun_out/octree_bench.json
 #   oprof      rocprofv3 stats + FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py   -> gpurun_out/oprof, opmc{1,2}
 #   pipeline   train -> eval -> extraction -> optimization -> evaluation through the drop-in CLIs -> gpurun_out/converge.log
+#   formats    the five CLIs on the analytic scene exported in the reference's ON-DISK formats (scripts/export_scene.py): NeRF-Synthetic
+#              directory (100 x 800 x 800 RGBA PNGs, --config blender) and NSVF directory (100 x 1920 x 1080, SH25 tt preset with
+#              the scene's near / far), next to the same run on datasets.Synthetic            -> gpurun_out/pipeline_cli_{blender,nsvf,synthetic*}.log
 #   power      clocks / power sampled while a long bench runs                               -> gpurun_out/smi.log
 #   probe      scripts/contention_probe.py: a stand-in for a collective's kernel beside the step  -> gpurun_out/contention_probe.jsonl
 #   tune       scripts/tune_ab.py $TUNE_ARGS: in-process A/B of pxo_set_tuning variants            -> gpurun_out/tune_ab.jsonl
@@ -140,6 +143,38 @@ for stage in ${STAGES:-tests bench}; do
     timeout 300 python -m plenoctree_amd.octree.optimization $C --input /tmp/pxo_conv/tree.npz --output /tmp/pxo_conv/tree_opt.npz --num_epochs ${OPT_EPOCHS:-4} --val_interval 2 >> gpurun_out/converge.log 2>&1; echo "optimization exit $?"
     timeout 200 python -m plenoctree_amd.octree.evaluation $C --input /tmp/pxo_conv/tree_opt.npz >> gpurun_out/converge.log 2>&1; echo "evaluation exit $?"
     grep -v amdgpu.ids gpurun_out/converge.log | tail -45 ;;
+  formats)
+    D=/tmp/pxo_formats; rm -rf $D; mkdir -p $D
+    STEPS=${PIPE_STEPS:-3000}
+    timeout 600 python scripts/export_scene.py blender $D/scene_blender --size 800 800 --views 100 8 8 > gpurun_out/export_scene.log 2>&1; echo "export blender exit $?"
+    timeout 900 python scripts/export_scene.py nsvf $D/scene_nsvf --size 1080 1920 --views 100 8 8 >> gpurun_out/export_scene.log 2>&1; echo "export nsvf exit $?"
+    du -sh $D/scene_blender $D/scene_nsvf | tee -a gpurun_out/export_scene.log
+    common='image_batching: false\nfactor: 0\nnum_coarse_samples: 64\nnum_fine_samples: 128\nuse_viewdirs: false\nwhite_bkgd: true\nbatch_size: 4096\nrandomized: true\nnear: 2.0\nfar: 6.0\nprint_every: 500\nrender_every: 100000\nchunk: 8192\n'
+    for run in blender synthetic_as_blender nsvf synthetic_as_nsvf; do
+      T=$D/train_$run; mkdir -p $T
+      case $run in
+        blender) printf "dataset: blender\nsh_deg: 3\n$common" > $T/cfg.yaml; DD="--data_dir $D/scene_blender" ;;
+        synthetic_as_blender) printf "dataset: synthetic\nsynthetic_8bit: true\nsynthetic_views: [100, 8]\nsh_deg: 3\n$common" > $T/cfg.yaml; DD="" ;;
+        nsvf) printf "dataset: nsvf\nsh_deg: 4\nsparsity_radius: 1.5\nsparsity_length: 0.05\n$common" > $T/cfg.yaml; DD="--data_dir $D/scene_nsvf" ;;
+        synthetic_as_nsvf) printf "dataset: synthetic\nsynthetic_8bit: true\nsynthetic_views: [100, 8]\nsynthetic_hw: [1080, 1920]\nsh_deg: 4\nsparsity_radius: 1.5\nsparsity_length: 0.05\n$common" > $T/cfg.yaml; DD="" ;;
+      esac
+      printf "max_steps: $STEPS\nsave_every: $STEPS\n" >> $T/cfg.yaml
+      C="--train_dir $T --config $T/cfg.yaml $DD"
+      L=gpurun_out/pipeline_cli_$run.log; : > $L
+      ( echo "### cfg.yaml"; cat $T/cfg.yaml; [ -n "$DD" ] && echo "### data_dir: $(ls ${DD#--data_dir } | head -8 | tr '\n' ' ')" ) >> $L
+      timeout 900 python -m plenoctree_amd.nerf_sh.train $C >> $L 2>&1; echo "$run train exit $?"
+      timeout 600 python -m plenoctree_amd.nerf_sh.eval $C --save_output false >> $L 2>&1; echo "$run eval exit $?"
+      timeout 600 python -m plenoctree_amd.octree.extraction $C --init_grid_depth 8 --output $T/tree.npz >> $L 2>&1; echo "$run extraction exit $?"
+      timeout 600 python -m plenoctree_amd.octree.optimization $C --input $T/tree.npz --output $T/tree_opt.npz --num_epochs ${OPT_EPOCHS:-2} --val_interval 1 >> $L 2>&1; echo "$run optimization exit $?"
+      timeout 600 python -m plenoctree_amd.octree.evaluation $C --input $T/tree_opt.npz >> $L 2>&1; echo "$run evaluation exit $?"
+      grep -v amdgpu.ids $L | grep -iE "psnr|rays/s|exit|ssim|error|Traceback" | tail -25
+    done
+    # the PSNR lines of the on-disk runs next to those of the same scene through datasets.Synthetic: they must be the same lines
+    for pair in "blender synthetic_as_blender" "nsvf synthetic_as_nsvf"; do
+      set -- $pair
+      echo "== $1 vs $2 (PSNR lines that differ; none = identical)"
+      diff <(grep -iE "psnr" gpurun_out/pipeline_cli_$1.log | grep -v "rays/s") <(grep -iE "psnr" gpurun_out/pipeline_cli_$2.log | grep -v "rays/s") | head -20
+    done ;;
   power)
     ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Power|mclk|Temperature \(Sensor (edge|junction)" | tr '\n' ' ' ; echo; sleep 0.5; done ) > gpurun_out/smi.log &
     timeout 120 python bench.py --steps 400 --warmup 3 $HEAD_ARGS > gpurun_out/bench_long.json 2> gpurun_out/bench_long.err

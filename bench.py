@@ -643,9 +643,7 @@ def run_octree(job, a):
     keep = ("basis_dim", "reso", "image", "cams", "step_size", "grid_weight_render_ms_per_cam", "grid_weight_roofline", "mask_voxels",
             "tree_build_ms", "n_internal", "sample_cells_ms", "sample_points", "render_exact_ms_per_image", "render_exact_roofline",
             "render_fast_ms_per_image", "render_fast_roofline", "render_bwd_ms_per_image", "render_bwd_roofline",
-            "render_bwd_reusing_fwd_ms_per_image", "render_bwd_reusing_fwd_roofline", "render_bwd_leaf_major_ms_per_image",
-            "render_bwd_leaf_major_roofline", "render_bwd_leaf_major_vs_ray_major_rel_l1", "render_bwd_leaf_major_fallback_records",
-            "sgd_ms", "sgd_roofline", "tree_data_MB")
+            "render_bwd_reusing_fwd_ms_per_image", "render_bwd_reusing_fwd_roofline", "sgd_ms", "sgd_roofline", "tree_data_MB")
     rec = {k: m[k] for k in keep if k in m}
     for k, v in rec.items():                      # the per-image work counts stay in profiles/*_octree_bench.json
         if isinstance(v, dict) and "per_image" in v:

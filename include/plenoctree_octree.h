@@ -147,21 +147,6 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
                           const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
                           const float* grad_out, float* grad_data, void* stream);
 
-/* The same gradient, LEAF-MAJOR (csrc/octree_kernels.hip, "leaf-major gradient"): a sample's gradient row is rank one, so the
- * march emits 24-byte records (leaf, ray, 4 floats), a counting sort bins them by 2^9 (SH25: 2^8) consecutive leaf cells, and one
- * workgroup per bin accumulates its rows in LDS and adds each touched row to grad_data ONCE with plain stores -- no global
- * float atomics.  Same semantics as pxo_octree_render_bwd (accumulates into grad_data; exact marching); out_rgb is REQUIRED.
- * ws: pxo_octree_render_bwd_binned_workspace_bytes(tree, B, max_records) bytes, max_records = an upper estimate of the samples
- * above sigma_thresh over the B rays (pxo_octree_count_work's counts[2], or ~64 B as a rule).  If it is too small nothing is
- * lost: waves that find no room add their rows with atomics like the ray-major kernel (slower);
- * pxo_octree_render_bwd_binned_status (synchronises `stream`) reports the records emitted and those that took that path. */
-int pxo_octree_render_bwd_binned_workspace_bytes(const PxoTree* tree, int64_t B, int64_t max_records, size_t* bytes);
-int pxo_octree_render_bwd_binned(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
-                                 const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
-                                 const float* grad_out, float* grad_data, int64_t max_records, void* ws, size_t ws_bytes,
-                                 void* stream);
-int pxo_octree_render_bwd_binned_status(const PxoTree* tree, int64_t B, int64_t max_records, const void* ws, size_t ws_bytes,
-                                        int64_t* records, int64_t* fallback_records, void* stream);
 
 /* ---- work counters of the marchers (roofline pass: scripts/octree_bench.py states each kernel's algorithmic bytes from
  *      these; nothing on the product path calls them) ----

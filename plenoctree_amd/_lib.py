@@ -144,10 +144,6 @@ SIGNATURES = {
                                       POINTER(PxoRenderOpts), P, P]),
     "pxo_octree_render_bwd": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64,
                                       POINTER(PxoRenderOpts), P, P, P, P]),
-    "pxo_octree_render_bwd_binned_workspace_bytes": (c_int, [POINTER(PxoTree), c_int64, c_int64, POINTER(c_size_t)]),
-    "pxo_octree_render_bwd_binned": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), P, P, P, c_int64, POINTER(PxoRenderOpts), P, P, P,
-                                             c_int64, P, c_size_t, P]),
-    "pxo_octree_render_bwd_binned_status": (c_int, [POINTER(PxoTree), c_int64, c_int64, P, c_size_t, POINTER(c_int64), POINTER(c_int64), P]),
     "pxo_octree_count_work": (c_int, [POINTER(PxoTree), POINTER(PxoCamera), POINTER(PxoRenderOpts), P, P, P]),
     "pxo_grid_weight_count_work": (c_int, [P, c_int, P, c_int, c_float, c_float, c_int, c_int, POINTER(PxoRenderOpts),
                                            F3, F3, P, P, P]),

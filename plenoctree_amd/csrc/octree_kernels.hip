@@ -1392,355 +1392,6 @@ __global__ __launch_bounds__(kRenderThreads) void octree_render_bwd4_kernel(Rend
 }
 
 // ------------------------------------------------------------------------------------------
-// leaf-major gradient (pxo_octree_render_bwd_binned)
-// ------------------------------------------------------------------------------------------
-// The ray-major kernel above is bound by its evicted rows: ~13 M read-modify-write rows of 196 B per 800 x 800 image through
-// the L2's atomic units (profiles/r05*_octree_kernels.md).  The gradient row of a sample is RANK ONE -- (e_r, e_g, e_b) (x)
-// basis(ray) plus e_sigma -- so what a sample contributes is a 24-byte record (leaf, ray, 4 floats), not a row.  Three
-// launches:
-//   1 octree_bwd_records_kernel   the backward's march (the same samples, the same arithmetic) EMITS records into 128-record
-//                                 chunks a wave reserves with one atomic each, and counts them per BIN of 2^shift consecutive
-//                                 leaf cells (levels are stored in Morton order: a bin is a small cube of space);
-//   2 bin_scan / bin_scatter      exclusive scan over the bins, records to their bin's slice (counting sort);
-//   3 octree_bwd_bins_kernel      one workgroup per occupied bin adds its records' rank-one rows into the bin's rows in LDS
-//                                 (4 lanes per record, the basis recomputed from the ray id) and adds every TOUCHED row to
-//                                 grad_data once, with plain loads and stores: the bin is the workgroup's alone.
-// No global float atomics on the fast path.  A wave that cannot get a chunk (workspace too small) adds its rows with atomics
-// as the ray-major kernel would: slower, still correct; the count is returned by pxo_octree_render_bwd_binned_status.
-struct BwdRecord { int leaf; int ray; float e0, e1, e2, es; };      // 24 B
-static_assert(sizeof(BwdRecord) == 24, "record layout");
-constexpr int kRecChunk = 128;
-
-struct BinnedWs {
-  unsigned int* scalars;       // [0] chunks handed out, [1] records that took the atomic fallback, [2] records emitted
-  unsigned int* chunk_count;   // [max_chunks] records in chunk c
-  unsigned int* hist;          // [nbins]
-  unsigned int* off;           // [nbins + 1] exclusive scan of hist
-  unsigned int* cursor;        // [nbins]
-  BwdRecord* raw;              // [max_chunks * kRecChunk]
-  BwdRecord* sorted;           // [max_chunks * kRecChunk]
-  int64_t max_chunks, nbins;
-  int shift;
-  size_t total;
-};
-static int binned_shift(int data_dim) { return data_dim * 4 * 512 <= 110 * 1024 ? 9 : 8; }     // rows of a bin live in LDS
-static BinnedWs binned_ws(const PxoTree* tree, int64_t n_rays, int64_t max_records, void* ws) {
-  BinnedWs w;
-  w.shift = binned_shift(tree->data_dim);
-  w.nbins = ((tree->n_internal * 8) >> w.shift) + 1;
-  w.max_chunks = (max_records + kRecChunk - 1) / kRecChunk + (n_rays + 15) / 16 + 1;    // every wave may leave one chunk part-filled
-  char* base = reinterpret_cast<char*>(ws);
-  size_t o = 0;
-  auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o = (o + bytes + 255) & ~(size_t)255; return p; };
-  w.scalars = reinterpret_cast<unsigned int*>(take(64));
-  w.chunk_count = reinterpret_cast<unsigned int*>(take((size_t)w.max_chunks * 4));
-  w.hist = reinterpret_cast<unsigned int*>(take((size_t)w.nbins * 4));
-  w.off = reinterpret_cast<unsigned int*>(take((size_t)(w.nbins + 1) * 4));
-  w.cursor = reinterpret_cast<unsigned int*>(take((size_t)w.nbins * 4));
-  w.raw = reinterpret_cast<BwdRecord*>(take((size_t)w.max_chunks * kRecChunk * sizeof(BwdRecord)));
-  w.sorted = reinterpret_cast<BwdRecord*>(take((size_t)w.max_chunks * kRecChunk * sizeof(BwdRecord)));
-  w.total = o;
-  return w;
-}
-
-// launch 1: the march of octree_render_bwd4_kernel's second pass (out_rgb given), records instead of rows
-template <int KF>
-__global__ __launch_bounds__(kRenderThreads) void octree_bwd_records_kernel(RenderArgs A, const float* __restrict__ fwd_rgb,
-                                                                             const float* __restrict__ grad_out,
-                                                                             float* __restrict__ grad_data, BinnedWs W) {
-  using G = RowGeom<4>;
-  constexpr int kRow = 4, kRaysPerBlock = G::kRaysPerBlock;
-  __shared__ int s_stack[kRaysPerBlock][kMaxD + 2];
-  __shared__ float s_basis[kRaysPerBlock][25];
-  const int row = threadIdx.x / kRow, l = threadIdx.x % kRow, lane = threadIdx.x & 63;
-  int64_t ray = 0;
-  float origin[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 1.f}, vdir[3] = {0.f, 0.f, 1.f};
-  bool active = true;
-  if (A.has_cam) {
-    const int Wd = A.cam.width, H = A.cam.height;
-    const int tiles_x = (Wd + 2 * G::kWTX - 1) / (2 * G::kWTX);
-    const int bx = (int)(blockIdx.x % tiles_x), by = (int)(blockIdx.x / tiles_x);
-    const int wv = row / G::kRaysPerWave, q = row % G::kRaysPerWave;
-    const int px = (bx * 2 + (wv & 1)) * G::kWTX + q % G::kWTX, py = (by * 2 + (wv >> 1)) * G::kWTY + q / G::kWTX;
-    active = px < Wd && py < H;
-    ray = (int64_t)py * Wd + px;
-    if (active) {
-      camera_ray(A.cam.c2w, A.cam.fx, A.cam.fy, Wd, H, px, py, origin, dir);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) vdir[a] = dir[a];
-    }
-  } else {
-    ray = blockIdx.x * (int64_t)kRaysPerBlock + row;
-    active = ray < A.B;
-    if (active) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        origin[a] = A.origins[ray * 3 + a];
-        dir[a] = A.dirs[ray * 3 + a];
-        vdir[a] = A.viewdirs[ray * 3 + a];
-      }
-    }
-  }
-  const int K = A.tree.basis_dim, D = A.tree.data_dim;
-  const int Kc = KF > 0 ? KF : K;
-  TreeRay r;
-  to_tree_ray(origin, dir, A.tree.offset, A.tree.invradius, r);
-  CellExit cell_exit;
-  cell_exit.init(r.invdir);
-  const bool alive = active && !(r.tmax < 0.0f || r.tmin > r.tmax);
-  if (l == 0) {
-    if (alive) sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], s_basis[row]);
-    else
-      for (int i = 0; i < 25; ++i) s_basis[row][i] = 0.0f;
-  }
-  __builtin_amdgcn_wave_barrier();
-  constexpr int kChM = ((KF > 0 ? KF / 4 : 6) + kRow - 1) / kRow > 0 ? ((KF > 0 ? KF / 4 : 6) + kRow - 1) / kRow : 1;
-  const int chG = Kc >> 2, chR = Kc & 3;
-  float bk[4 * kChM], bk_r = 0.0f;
-#pragma unroll
-  for (int m = 0; m < kChM; ++m)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bk[4 * m + e] = (l + kRow * m) < chG ? s_basis[row][4 * (l + kRow * m) + e] : 0.0f;
-  if (l < chR) bk_r = s_basis[row][4 * chG + l];
-  const float* __restrict__ data = A.tree.data;
-  const int32_t* __restrict__ child = A.tree.child;
-  float g[3] = {0.f, 0.f, 0.f};
-  float accum = 0.0f;
-  if (alive) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] = grad_out[ray * 3 + c];
-    accum = (g[0] * fwd_rgb[ray * 3] + g[1] * fwd_rgb[ray * 3 + 1]) + g[2] * fwd_rgb[ray * 3 + 2];
-  }
-  // the wave's chunk: wave-uniform (every lane carries the same values)
-  int chunk = -1, used = kRecChunk;           // no chunk yet
-  unsigned emitted = 0, fallback = 0;
-  Marcher mk;
-  mk.init(s_stack[row]);
-  float t = r.tmin, light = 1.0f;
-  bool running = alive && t < r.tmax;
-  while (__builtin_amdgcn_ballot_w64(running) != 0) {
-    bool has = false;
-    int leaf_i = 0;
-    float e0 = 0.f, e1 = 0.f, e2 = 0.f, es = 0.f;
-    if (running) {
-      float pos[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) pos[a] = clamp_coord(r.o[a] + t * r.d[a]);
-      int depth;
-      const int64_t leaf = mk.find(child, pos, depth);
-      const float cube = (float)(2u << depth);
-      float local[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) local[a] = __builtin_amdgcn_fractf(pos[a] * cube);
-      const float delta_t = cell_exit(local) * inv_cells(depth) + A.opt.step_size;
-      const float* __restrict__ val = data + leaf * D;
-      const float sg = val[D - 1];
-      if (sg > A.opt.sigma_thresh) {
-        const float dtw = delta_t * r.delta_scale;
-        const float att = expf(-dtw * sg);
-        const float weight = light * (1.0f - att);
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < kChM; ++m) {
-          const int gi = l + kRow * m;
-          if (gi < chG) {
-            const f32x4u c0 = *reinterpret_cast<const f32x4u*>(val + 4 * gi);
-            const f32x4u c1 = *reinterpret_cast<const f32x4u*>(val + Kc + 4 * gi);
-            const f32x4u c2 = *reinterpret_cast<const f32x4u*>(val + 2 * Kc + 4 * gi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              p0 += c0[e] * bk[4 * m + e];
-              p1 += c1[e] * bk[4 * m + e];
-              p2 += c2[e] * bk[4 * m + e];
-            }
-          }
-        }
-        if (l < chR) {
-          const int k = 4 * chG + l;
-          p0 += val[k] * bk_r;
-          p1 += val[Kc + k] * bk_r;
-          p2 += val[2 * Kc + k] * bk_r;
-        }
-        p0 = row_sum<kRow>(p0);
-        p1 = row_sum<kRow>(p1);
-        p2 = row_sum<kRow>(p2);
-        const float c0 = 1.0f / (1.0f + expf(-p0)), c1 = 1.0f / (1.0f + expf(-p1)), c2 = 1.0f / (1.0f + expf(-p2));
-        const float total = (g[0] * c0 + g[1] * c1) + g[2] * c2;
-        e0 = weight * g[0] * c0 * (1.0f - c0);
-        e1 = weight * g[1] * c1 * (1.0f - c1);
-        e2 = weight * g[2] * c2 * (1.0f - c2);
-        light = light * att;
-        accum -= weight * total;
-        es = dtw * (total * light - accum);
-        leaf_i = (int)leaf;
-        has = true;
-      }
-      const float tn = t + delta_t;
-      running = tn > t && tn < r.tmax;
-      t = tn;
-    }
-    const uint64_t hm = __builtin_amdgcn_ballot_w64(has && l == 0);
-    if (hm == 0) continue;
-    const int n = __builtin_popcountll(hm);
-    if (used + n > kRecChunk) {
-      // close the chunk in use, take a new one (one atomic per 128 records of the wave)
-      if (chunk >= 0 && lane == 0) W.chunk_count[chunk] = (unsigned)used;
-      int id = 0;
-      if (lane == 0) {
-        id = (int)atomicAdd(&W.scalars[0], 1u);
-        if (id >= W.max_chunks) id = -1;
-      }
-      chunk = __builtin_amdgcn_readfirstlane(id);
-      used = 0;
-    }
-    if (chunk >= 0) {
-      if (has && l == 0) {
-        const int rank = __builtin_popcountll(hm & ((1ull << lane) - 1ull));
-        BwdRecord* rec = W.raw + (int64_t)chunk * kRecChunk + used + rank;
-        *reinterpret_cast<int2*>(rec) = make_int2(leaf_i, (int)ray);
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(rec) + 8) = make_float4(e0, e1, e2, es);
-        atomicAdd(&W.hist[leaf_i >> W.shift], 1u);
-      }
-      used += n;
-      emitted += (unsigned)n;
-    } else {
-      // no workspace left: this step's rows go to grad_data with atomics, every ray's 4 lanes on its own row
-      if (has) {
-        float* __restrict__ gv = grad_data + (int64_t)leaf_i * D;
-        for (int idx = l; idx < D - 1; idx += kRow) {
-          const int ch = idx / Kc;
-          unsafeAtomicAdd(gv + idx, s_basis[row][idx - ch * Kc] * (ch == 0 ? e0 : (ch == 1 ? e1 : e2)));
-        }
-        if (l == 0) unsafeAtomicAdd(gv + D - 1, es);
-      }
-      used = kRecChunk;            // keep asking: chunks do not come back, but the counter tells the host how many were missing
-      fallback += (unsigned)n;
-    }
-  }
-  if (chunk >= 0 && lane == 0) W.chunk_count[chunk] = (unsigned)used;
-  if (lane == 0) {
-    if (emitted) atomicAdd(&W.scalars[2], emitted);
-    if (fallback) atomicAdd(&W.scalars[1], fallback);
-  }
-}
-
-// launch 2a: exclusive scan of the bin counts (one workgroup; nbins is ~1e4)
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const unsigned int* __restrict__ hist, int64_t nbins,
-                                                        unsigned int* __restrict__ off, unsigned int* __restrict__ cursor) {
-  __shared__ unsigned int s_part[1024];
-  const int tid = threadIdx.x;
-  const int64_t per = (nbins + 1023) / 1024, b0 = tid * per, b1 = b0 + per < nbins ? b0 + per : nbins;
-  unsigned int sum = 0;
-  for (int64_t b = b0; b < b1; ++b) sum += hist[b];
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const unsigned int v = tid >= o ? s_part[tid - o] : 0u;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  unsigned int run = s_part[tid] - sum;          // exclusive prefix of this thread's range
-  for (int64_t b = b0; b < b1; ++b) {
-    off[b] = run;
-    cursor[b] = run;
-    run += hist[b];
-  }
-  if (tid == 1023) off[nbins] = s_part[1023];
-}
-
-// launch 2b: records to their bin's slice.  One thread per raw slot; the lanes of a wave that hold the same bin draw their
-// positions with ONE atomic (neighbouring records come from neighbouring rays: mostly one or two bins per wave)
-__global__ __launch_bounds__(256) void bin_scatter_kernel(BinnedWs W) {
-  const int64_t slot = blockIdx.x * (int64_t)256 + threadIdx.x;
-  const int64_t chunk = slot / kRecChunk;
-  const unsigned n_chunks = W.scalars[0] < (unsigned)W.max_chunks ? W.scalars[0] : (unsigned)W.max_chunks;
-  bool valid = chunk < (int64_t)n_chunks && (unsigned)(slot - chunk * kRecChunk) < W.chunk_count[chunk];
-  BwdRecord rec = {0, 0, 0.f, 0.f, 0.f, 0.f};
-  if (valid) rec = W.raw[slot];
-  const int bin = valid ? rec.leaf >> W.shift : -1;
-  const int lane = threadIdx.x & 63;
-  unsigned pos = 0;
-  uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
-  while (todo) {
-    const int src = __builtin_ctzll(todo);
-    const int b = __builtin_amdgcn_readlane(bin, src);
-    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && bin == b);
-    unsigned base = 0;
-    if (lane == src) base = atomicAdd(&W.cursor[b], (unsigned)__builtin_popcountll(same));
-    base = __builtin_amdgcn_readlane(base, src);
-    if (valid && bin == b) pos = base + (unsigned)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  if (valid) W.sorted[pos] = rec;
-}
-
-// launch 3: one workgroup per bin (16 waves: the records of a bin are one contiguous slice, read 256 at a time)
-constexpr int kBinThreads = 1024;
-template <int KF>
-__global__ __launch_bounds__(kBinThreads) void octree_bwd_bins_kernel(RenderArgs A, BinnedWs W, float* __restrict__ grad_data) {
-  extern __shared__ float s_rows[];              // [2^shift][D], one touched flag per row, one basis row per record in flight
-  const int D = A.tree.data_dim, K = KF > 0 ? KF : A.tree.basis_dim;
-  const int nrow = 1 << W.shift;
-  const int64_t bin = blockIdx.x;
-  const unsigned r0 = W.off[bin], r1 = W.off[bin + 1];
-  if (r0 == r1) return;
-  int* s_touched = reinterpret_cast<int*>(s_rows + nrow * D);
-  float* s_y = reinterpret_cast<float*>(s_touched + nrow) + (threadIdx.x >> 2) * 25;      // this record's basis values
-  for (int i = threadIdx.x; i < nrow * D; i += kBinThreads) s_rows[i] = 0.0f;
-  for (int i = threadIdx.x; i < nrow; i += kBinThreads) s_touched[i] = 0;
-  __syncthreads();
-  const int l = threadIdx.x & 3;
-  unsigned i = r0 + (threadIdx.x >> 2);
-  BwdRecord rec = {0, 0, 0.f, 0.f, 0.f, 0.f};
-  if (i < r1) rec = W.sorted[i];
-  while (i < r1) {
-    const BwdRecord cur = rec;
-    const unsigned nxt = i + kBinThreads / 4;
-    if (nxt < r1) rec = W.sorted[nxt];           // the next record travels while this one is added
-    if (l == 0) {
-      float vdir[3];
-      if (A.has_cam) {
-        float origin[3];
-        camera_ray(A.cam.c2w, A.cam.fx, A.cam.fy, A.cam.width, A.cam.height, cur.ray % A.cam.width, cur.ray / A.cam.width, origin, vdir);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) vdir[a] = A.viewdirs[(int64_t)cur.ray * 3 + a];
-      }
-      float Y[25];
-      sh_basis_dyn(K, vdir[0], vdir[1], vdir[2], Y);
-#pragma unroll
-      for (int q = 0; q < 25; ++q)
-        if (q < K) s_y[q] = Y[q];
-    }
-    __builtin_amdgcn_wave_barrier();             // (the four lanes of a record sit in one wave; its LDS operations execute in order)
-    const int lr = cur.leaf & (nrow - 1);
-    float* rowp = s_rows + lr * D;
-    // lane l of the record's four: data indices l, l + 4, ... (channel-major rows: index = channel * K + k)
-    for (int idx = l; idx < D - 1; idx += 4) {
-      const int ch = idx / K, k = idx - ch * K;
-      __hip_atomic_fetch_add(rowp + idx, s_y[k] * (ch == 0 ? cur.e0 : (ch == 1 ? cur.e1 : cur.e2)), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (l == 0) {
-      __hip_atomic_fetch_add(rowp + D - 1, cur.es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      s_touched[lr] = 1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    i = nxt;
-  }
-  __syncthreads();
-  // every touched row is added to grad_data once (plain loads and stores: nobody else owns this bin); wave w takes rows w, w + 16, ..
-  const int64_t cell0 = bin << W.shift, n_cells = A.tree.n_internal * 8;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int rw = wave; rw < nrow; rw += kBinThreads / 64) {
-    if (!s_touched[rw] || cell0 + rw >= n_cells) continue;
-    float* __restrict__ gp = grad_data + (cell0 + rw) * D;
-    for (int j = lane; j < D; j += 64) gp[j] += s_rows[rw * D + j];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // work counters (roofline pass, scripts/octree_bench.py): the marchers' own ray set-up, leaf lookup, step rule and
 // early stop -- same arithmetic, so the same sample sequence -- counting instead of shading.  One thread per ray.
 //   counts[0] rays that enter the volume      counts[2] samples above sigma_thresh (one full row / one weight update each)
@@ -2273,71 +1924,6 @@ int pxo_octree_render_bwd(const PxoTree* tree, const PxoCamera* cam, const float
     default: hipLaunchKernelGGL((octree_render_kernel<1, 16>), dim3(grid), dim3(kRenderThreads), 0, (hipStream_t)stream, A, (float*)nullptr, out_rgb, grad_out, grad_data); break;
   }
   return check_launch("octree_render_bwd");
-}
-
-int pxo_octree_render_bwd_binned_workspace_bytes(const PxoTree* tree, int64_t B, int64_t max_records, size_t* bytes) {
-  PXO_REQUIRE(tree && bytes && B >= 0 && max_records >= 0, "pxo_octree_render_bwd_binned_workspace_bytes: bad arguments");
-  PXO_REQUIRE(tree->n_internal >= 1 && tree->n_internal < ((int64_t)1 << 28) && tree->data_dim >= 4 && tree->data_dim <= 76,
-              "pxo_octree_render_bwd_binned_workspace_bytes: bad tree");
-  *bytes = binned_ws(tree, B, max_records, nullptr).total;
-  return PXO_OK;
-}
-
-int pxo_octree_render_bwd_binned(const PxoTree* tree, const PxoCamera* cam, const float* origins, const float* dirs,
-                                 const float* viewdirs, int64_t B, const PxoRenderOpts* opts, const float* out_rgb,
-                                 const float* grad_out, float* grad_data, int64_t max_records, void* ws, size_t ws_bytes,
-                                 void* stream) {
-  RenderArgs A;
-  unsigned grid;
-  int row;
-  if (int rc = render_args(tree, cam, origins, dirs, viewdirs, B, opts, "pxo_octree_render_bwd_binned", true, A, grid, row)) return rc;
-  if (B == 0) return PXO_OK;
-  PXO_REQUIRE(grad_out && grad_data && out_rgb && ws, "pxo_octree_render_bwd_binned: null pointer (out_rgb, the exact forward image, is required)");
-  PXO_REQUIRE(opts->stop_thresh == 0.0f, "pxo_octree_render_bwd_binned: out_rgb must come from an exact march (stop_thresh == 0), got %g",
-              (double)opts->stop_thresh);
-  PXO_REQUIRE(max_records >= 0 && B < ((int64_t)1 << 31), "pxo_octree_render_bwd_binned: bad sizes");
-  const BinnedWs W = binned_ws(tree, B, max_records, ws);
-  if (ws_bytes < W.total) { set_error("pxo_octree_render_bwd_binned: workspace %zu < %zu", ws_bytes, W.total); return PXO_ERR_WORKSPACE; }
-  hipStream_t s = (hipStream_t)stream;
-  // scalars, (chunk counts need no zeroing: every chunk handed out gets its count), bin histogram
-  if (hipMemsetAsync(W.scalars, 0, 64, s) != hipSuccess || hipMemsetAsync(W.hist, 0, (size_t)W.nbins * 4, s) != hipSuccess) {
-    set_error("pxo_octree_render_bwd_binned: hipMemsetAsync failed");
-    return PXO_ERR_HIP;
-  }
-  // 4 lanes per ray: the launch geometry of the 4-lane march (8 x 8 pixels or 64 rays per block), whatever `row` says
-  grid = cam ? (unsigned)(((cam->width + 7) / 8) * (int64_t)((cam->height + 7) / 8)) : (unsigned)blocks_for(B, kRenderThreads / 4);
-  const int shmem = ((1 << W.shift) * tree->data_dim + (1 << W.shift) + (kBinThreads / 4) * 25) * 4;
-#define PXO_BINNED(KF_)                                                                                                            \
-  do {                                                                                                                             \
-    hipLaunchKernelGGL((octree_bwd_records_kernel<KF_>), dim3(grid), dim3(kRenderThreads), 0, s, A, out_rgb, grad_out, grad_data, W); \
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, W.hist, W.nbins, W.off, W.cursor);                              \
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)((W.max_chunks * kRecChunk + 255) / 256)), dim3(256), 0, s, W);           \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&octree_bwd_bins_kernel<KF_>), hipFuncAttributeMaxDynamicSharedMemorySize, shmem); \
-    hipLaunchKernelGGL((octree_bwd_bins_kernel<KF_>), dim3((unsigned)W.nbins), dim3(kBinThreads), shmem, s, A, W, grad_data);       \
-  } while (0)
-  switch (tree->basis_dim) {
-    case 16: PXO_BINNED(16); break;
-    case 25: PXO_BINNED(25); break;
-    default: PXO_BINNED(-1); break;
-  }
-#undef PXO_BINNED
-  return check_launch("octree_render_bwd_binned");
-}
-
-int pxo_octree_render_bwd_binned_status(const PxoTree* tree, int64_t B, int64_t max_records, const void* ws, size_t ws_bytes,
-                                        int64_t* records, int64_t* fallback_records, void* stream) {
-  PXO_REQUIRE(tree && ws && records && fallback_records, "pxo_octree_render_bwd_binned_status: null pointer");
-  const BinnedWs W = binned_ws(tree, B, max_records, const_cast<void*>(ws));
-  if (ws_bytes < W.total) { set_error("pxo_octree_render_bwd_binned_status: workspace %zu < %zu", ws_bytes, W.total); return PXO_ERR_WORKSPACE; }
-  unsigned int host[4] = {0, 0, 0, 0};
-  if (hipMemcpyAsync(host, W.scalars, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
-    set_error("pxo_octree_render_bwd_binned_status: copy back failed");
-    return PXO_ERR_HIP;
-  }
-  *records = (int64_t)host[2];
-  *fallback_records = (int64_t)host[1];
-  return PXO_OK;
 }
 
 int pxo_octree_count_work(const PxoTree* tree, const PxoCamera* cam, const PxoRenderOpts* opts, unsigned long long* counts,

@@ -187,42 +187,6 @@ def octree_render_persp_bwd(tree, c2w, width, height, fx, opts, grad_out, grad_d
     return grad_data
 
 
-class BinnedBackward:
-    """Workspace + calls of the leaf-major gradient (pxo_octree_render_bwd_binned): records binned by leaf block, every touched
-    gradient row added once with plain stores.  `max_records`: an upper estimate of the samples above sigma_thresh of one
-    image (octree_count_work(...)["shaded_samples"], or 64 per ray by default); too small only costs speed."""
-
-    def __init__(self, tree, n_rays, max_records=None, device=None):
-        _require_gpu()
-        self.n_rays = int(n_rays)
-        self.max_records = int(max_records if max_records is not None else 64 * n_rays)
-        n = ctypes.c_size_t(0)
-        check(_lib.load().pxo_octree_render_bwd_binned_workspace_bytes(ctypes.byref(tree), self.n_rays, self.max_records, ctypes.byref(n)),
-              "pxo_octree_render_bwd_binned_workspace_bytes")
-        self.ws = torch.empty(max(n.value, 16), dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
-
-    def persp(self, tree, c2w, width, height, fx, opts, grad_out, grad_data, out_rgb, fy=None):
-        cam, keep = _camera(c2w, width, height, fx, fy)
-        check(_lib.load().pxo_octree_render_bwd_binned(ctypes.byref(tree), ctypes.byref(cam), None, None, None, width * height,
-                                                       ctypes.byref(opts), _f(out_rgb), _f(grad_out), _f(grad_data), self.max_records,
-                                                       _p(self.ws), self.ws.numel(), _stream()), "pxo_octree_render_bwd_binned")
-        return grad_data
-
-    def rays(self, tree, origins, dirs, viewdirs, opts, grad_out, grad_data, out_rgb):
-        check(_lib.load().pxo_octree_render_bwd_binned(ctypes.byref(tree), None, _f(origins), _f(dirs), _f(viewdirs), origins.shape[0],
-                                                       ctypes.byref(opts), _f(out_rgb), _f(grad_out), _f(grad_data), self.max_records,
-                                                       _p(self.ws), self.ws.numel(), _stream()), "pxo_octree_render_bwd_binned")
-        return grad_data
-
-    def status(self, tree):
-        """(records emitted, records that took the atomic fallback) of the last call; synchronises."""
-        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(_lib.load().pxo_octree_render_bwd_binned_status(ctypes.byref(tree), self.n_rays, self.max_records, _p(self.ws),
-                                                              self.ws.numel(), ctypes.byref(a), ctypes.byref(b), _stream()),
-              "pxo_octree_render_bwd_binned_status")
-        return a.value, b.value
-
-
 def octree_count_work(tree, c2w, width, height, fx, opts, fy=None, count_leaves=True):
     """Work counters of one render of `tree` from camera c2w (pxo_octree_count_work: the renderer's own march, counting):
     dict(rays, samples, shaded_samples, child_loads, distinct_leaves).  A roofline / debug pass, not on the product path."""

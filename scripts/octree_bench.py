@@ -219,36 +219,6 @@ def measure(a):
             extra = W * H * (24 if reuse else 12) + avg["distinct_leaves"] * D * 4 * 2
             out[f"{key}_roofline"] = roofline(marches * (alg_f - W * H * 12) + extra, floor_f - W * H * 12 + extra, ms,
                                               dict(avg, marches=marches), "octree_render_bwd4_kernel" if reuse else None)
-    # the leaf-major form of the same gradient (pxo_octree_render_bwd_binned): records binned by leaf block, rows added once
-    grad_ray_major = grad.clone()
-    shaded = int(counts["exact"][0]["shaded_samples"] * 1.15) if "exact" in counts else 64 * W * H
-    bb = oops.BinnedBackward(tree.view(), W * H, max_records=shaded, device=dev)
-
-    def bwd_binned():
-        for c, imc in zip(cams, ims):
-            _, g = oops.image_mse(imc, gt)
-            bb.persp(tree.view(), c, W, H, focal, r._opts(False), g, grad, imc)
-    grad.zero_()
-    bwd_binned()
-    rec, fb = bb.status(tree.view())
-    grad_leaf_major = grad.clone()
-    grad.zero_(); bwd(True)
-    den = float(grad.double().abs().sum())
-    out["render_bwd_leaf_major_vs_ray_major_rel_l1"] = float((grad_leaf_major.double() - grad.double()).abs().sum()) / max(den, 1e-30)
-    ms = timed(bwd_binned, reps=a.reps) / a.cams
-    out["render_bwd_leaf_major_ms_per_image"] = ms
-    out["render_bwd_leaf_major_records_last_image"] = rec
-    out["render_bwd_leaf_major_fallback_records"] = fb
-    out["render_bwd_leaf_major_workspace_MB"] = bb.ws.numel() / 1e6
-    if "exact" in counts:
-        avg, alg_f, floor_f = counts["exact"]
-        D = tree.data_dim
-        # algorithmic bytes of THIS form: the march's reads, a 24-byte record per shaded sample written, re-read, re-written and
-        # read again (counting sort + accumulation), every touched gradient row read-modify-written once; same floor as above
-        alg = (alg_f - W * H * 12) + W * H * 24 + avg["shaded_samples"] * 24 * 4 + avg["distinct_leaves"] * D * 4 * 2
-        out["render_bwd_leaf_major_roofline"] = roofline(alg, floor_f - W * H * 12 + W * H * 24 + avg["distinct_leaves"] * D * 4 * 2, ms,
-                                                         dict(avg, marches=1), None)
-    del grad_ray_major, grad_leaf_major
     out["grad_abs_sum"] = float(grad.double().abs().sum())
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
     out["tree_data_MB"] = tree.data.numel() * 4 / 1e6

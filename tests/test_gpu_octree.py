@@ -350,54 +350,6 @@ def test_octree_render_gradient_matches_oracle(K, bwd_update):
     close("image_mse grad", gi, ref_in.grad, rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("K,depth", [(4, 2), (16, 2), (25, 2), (16, 5)])
-def test_octree_render_gradient_leaf_major(K, depth):
-    """pxo_octree_render_bwd_binned (records binned by leaf block, rows added once with plain stores) against the oracle's
-    autograd gradient at the bounds of test_octree_render_gradient_matches_oracle, against the ray-major kernel on a deeper tree
-    (several bins), with accumulation, camera mode, and a workspace that is far too small (atomic fallback: same gradient)."""
-    oops = _oops(); dev = _gpu()
-    t = _random_tree(depth, 60 + K + depth, K, p=0.3 if depth <= 2 else 0.5)
-    view, (child, data) = _device_tree(t, dev)
-    rs = np.random.RandomState(K + 7)
-    B = 24 if depth <= 2 else 3000
-    o = (rs.randn(B, 3) * 3.0).astype(f32)
-    d = (-o + rs.randn(B, 3) * 0.3).astype(f32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    g = rs.randn(B, 3).astype(f32)
-    to = lambda a: torch.from_numpy(a).to(dev)
-    ropt = oops.render_opts(1e-3)
-    fwd = oops.octree_render_rays(view, to(o), to(d), to(d), ropt)
-    ref = torch.zeros_like(data)
-    oops.octree_render_rays_bwd(view, to(o), to(d), to(d), ropt, to(g), ref, out_rgb=fwd)
-    scale = float(ref.abs().max())
-    assert scale > 1e-3
-    if depth <= 2:                      # the oracle's autograd (float64) on the small tree
-        dd = torch.tensor(t.data.astype(np.float64), requires_grad=True)
-        out = T.render_rays_torch(t, dd, o, d, d, T.RenderOptions(1e-3))
-        (out * torch.from_numpy(g.astype(np.float64))).sum().backward()
-        want = dd.grad.float()
-    else:
-        want = ref.cpu()
-    for max_records, expect_fallback in ((None, False), (1, True)):
-        bb = oops.BinnedBackward(view, B, max_records=max_records, device=dev)
-        grad = torch.zeros_like(data)
-        bb.rays(view, to(o), to(d), to(d), ropt, to(g), grad, fwd)
-        n_rec, n_fb = bb.status(view)
-        assert n_rec + n_fb > 0 and (n_fb > 0) == expect_fallback, (n_rec, n_fb)
-        close(f"SH{K} leaf-major d/d data (max_records {max_records})", grad, want, rtol=2e-3, atol=2e-6 * scale + 1e-7)
-        bb.rays(view, to(o), to(d), to(d), ropt, to(g), grad, fwd)          # accumulates
-        close("accumulated", grad, 2 * want, rtol=2e-3, atol=4e-6 * scale + 1e-7)
-    # camera mode against the ray-major kernel
-    W, H, fx = 40, 28, 36.0
-    c2w = torch.from_numpy(_pose(40.0, 25.0)).to(dev)
-    im = oops.octree_render_persp(view, c2w, W, H, fx, ropt)
-    gi = to(rs.randn(H, W, 3).astype(f32))
-    a = torch.zeros_like(data); b = torch.zeros_like(data)
-    oops.octree_render_persp_bwd(view, c2w, W, H, fx, ropt, gi, a, out_rgb=im)
-    oops.BinnedBackward(view, W * H, device=dev).persp(view, c2w, W, H, fx, ropt, gi, b, im)
-    close("camera mode: leaf-major vs ray-major", b, a, rtol=2e-3, atol=2e-6 * float(a.abs().max()) + 1e-7)
-
-
 @pytest.mark.parametrize("lanes", [4, 8, 16])
 def test_octree_render_every_lanes_per_ray_template(lanes):
     """The renderer is instantiated for 4, 8 and 16 lanes per ray (the default launches use 4: backward = 4-lane march + 16-lane cooperative scatter);

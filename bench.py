@@ -679,7 +679,7 @@ def main(argv=None):
     if a.tune:
         from plenoctree_amd import ops
         knobs = {"tile_sched": ops.TUNE_TILE_SCHED, "wgrad_ranges": ops.TUNE_WGRAD_RANGES,
-                 "wgrad_skinny_ranges": ops.TUNE_WGRAD_SKINNY_RANGES}
+                 "wgrad_skinny_ranges": ops.TUNE_WGRAD_SKINNY_RANGES, "coarse_stream": ops.TUNE_COARSE_REVERSE_STREAM}
         for kv in a.tune.split(","):
             k, _, v = kv.partition("=")
             if k not in knobs:

@@ -336,6 +336,11 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
 #define PXO_TUNE_TILE_SCHED 0
 #define PXO_TUNE_WGRAD_RANGES 1
 #define PXO_TUNE_WGRAD_SKINNY_RANGES 2   /* the same for the two skinny products (enc-based pair, heads): 1 .. 2 x number of CUs */
+/*   PXO_TUNE_COARSE_REVERSE_STREAM  0 (default): every launch of pxo_train_fwd_bwd* on the caller's stream.  1: the reverse pass of
+ *                          the coarse level runs on an internal low-priority side stream (created on first use) beside the fine
+ *                          level's forward and joins the caller's stream before the fine weight gradients; `grads0_ready` is
+ *                          then recorded on that side stream.  Bits unchanged; +0.2 % / +0.7 % at 512 / 4096 rays (r06b). */
+#define PXO_TUNE_COARSE_REVERSE_STREAM 3
 int pxo_set_tuning(int knob, int value);
 int pxo_get_tuning(int knob, int* value);
 

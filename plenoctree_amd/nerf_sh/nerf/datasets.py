@@ -231,7 +231,12 @@ class Synthetic(Dataset):
             self.images = torch.cat(chunks).contiguous()
 
     def _q8(self, rgb):
-        return (torch.round(rgb * 255.0) / 255.0) if self.quantize8 else rgb
+        if not self.quantize8:
+            return rgb
+        # k / 255 exactly as the loaders compute it (numpy float32 division of the decoded byte): a table, because torch divides
+        # by a scalar as a multiplication by its reciprocal on the device, which is 1 ulp off for some k
+        lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(rgb.device)
+        return lut[torch.round(rgb * 255.0).long().clamp_(0, 255)]
 
     def _render(self, image_index, ray_indices, rays):
         return self._q8(analytic_scene_rgb(rays.origins, rays.directions, self.white_bkgd)).contiguous()

@@ -124,15 +124,16 @@ for stage in ${STAGES:-tests bench}; do
     echo "octree_bench exit $?"; cat gpurun_out/octree_bench.json; tail -5 gpurun_out/octree_bench.err ;;
   oprof)
     cd /tmp
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/oprof" -o obench -- python "$R/scripts/octree_bench.py" --cams 4 > "$R/gpurun_out/oprof_bench.json" 2> "$R/gpurun_out/oprof.err"
+    # stats AND both counter passes on the scene of bench.py's `octree` record (--cams ${OCAMS:-4}): the tree depends on the camera set
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/oprof" -o obench -- python "$R/scripts/octree_bench.py" --cams ${OCAMS:-4} > "$R/gpurun_out/oprof_bench.json" 2> "$R/gpurun_out/oprof.err"
     echo "octree rocprof exit $?"; i=0
     for ctr in FETCH_SIZE WRITE_SIZE; do
       i=$((i+1))
-      timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/gpurun_out/opmc$i" -o pmc -- python "$R/scripts/octree_bench.py" --cams 2 > /dev/null 2> "$R/gpurun_out/opmc$i.err"
+      timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/gpurun_out/opmc$i" -o pmc -- python "$R/scripts/octree_bench.py" --cams ${OCAMS:-4} --no-roofline > "$R/gpurun_out/opmc$i.json" 2> "$R/gpurun_out/opmc$i.err"
       echo "octree pmc pass $i exit $?"
     done
     cd "$R"; find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
-    python scripts/summarize_octree_prof.py gpurun_out gpurun_out tmp ;;
+    python scripts/summarize_octree_prof.py gpurun_out gpurun_out ${OPROF_TAG:-tmp} ;;
   pipeline)
     mkdir -p /tmp/pxo_conv
     printf 'dataset: synthetic\nfactor: 0\nnum_coarse_samples: 64\nnum_fine_samples: 128\nuse_viewdirs: false\nwhite_bkgd: true\nbatch_size: 4096\nsh_deg: 3\nrandomized: true\nmax_steps: %s\nprint_every: 250\nsave_every: %s\nrender_every: 1000\nchunk: 8192\n' ${PIPE_STEPS:-3000} ${PIPE_STEPS:-3000} > /tmp/pxo_conv/cfg.yaml

@@ -46,12 +46,35 @@ PEAK_HBM_ACHIEVABLE_GBPS = 6300.0        # MI355X_MICROARCH.md: what a streaming
 PEAK_HBM_SPEC_GBPS = 8000.0              # the HBM3E specification
 
 
+SCENE = {}      # what the running measurement works on; filled by measure() as it builds the scene
+
+
+def scene_mismatch(doc_scene):
+    """Which keys of the counters' scene differ from the running one (a tree built from another camera set is another tree:
+    round 5 divided the bytes of a 1.06 GB tree by the floor of a 1.4 GB one and reported traffic below the floor)."""
+    bad = []
+    for k, v in SCENE.items():
+        if k not in doc_scene:
+            bad.append(f"{k}: not recorded")
+        elif isinstance(v, float):
+            if abs(doc_scene[k] - v) > 1e-3 * max(abs(v), 1.0):
+                bad.append(f"{k}: {doc_scene[k]} vs {v}")
+        elif doc_scene[k] != v:
+            bad.append(f"{k}: {doc_scene[k]} vs {v}")
+    return bad
+
+
 def hbm_traffic(kernel):
     """Measured HBM bytes per launch of `kernel` from the committed PMC passes of scripts/octree_bench.py
-    (profiles/octree_hbm_traffic.json, written by scripts/summarize_octree_prof.py); None if absent."""
+    (profiles/octree_hbm_traffic.json, written by scripts/summarize_octree_prof.py); None if absent -- and a refusal (dict with
+    only `refused`) when those passes ran on a different scene than this run's."""
     try:
         with open(os.path.join(ROOT, "profiles", "octree_hbm_traffic.json")) as f:
             doc = json.load(f)
+        bad = scene_mismatch(doc.get("scene", {}))
+        if bad:
+            return {"refused": "profiles/octree_hbm_traffic.json was collected on another scene (" + "; ".join(bad) +
+                               "): no traffic ratio is computed from it"}
         k = doc["kernels"][kernel]
         per = float(k.get("cameras_per_launch", 1))          # the weight mask's launch serves several cameras; its roofline is per camera
         return {"read_bytes": k["hbm_read_bytes_per_launch"] / per, "write_bytes": k["hbm_write_bytes_per_launch"] / per,
@@ -69,7 +92,10 @@ def roofline(alg_bytes, floor_bytes, ms, parts, kernel=None):
     if kernel:
         r["kernel"] = kernel
         t = hbm_traffic(kernel)
-        if t:
+        if t and "refused" in t:
+            r["traffic"] = None
+            r["traffic_refused"] = t["refused"]
+        elif t:
             r["traffic"] = t["read_bytes"] + t["write_bytes"]
             r["traffic_over_floor"] = r["traffic"] / max(floor_bytes, 1)
             r["traffic_detail"] = t
@@ -134,6 +160,8 @@ def measure(a):
     rs = np.random.RandomState(7)
     cams = torch.from_numpy(np.stack([pose_spherical(rs.uniform(0, 360), rs.uniform(-10, 60), 4.0311) for _ in range(a.cams)])).to(dev)
     out = {"sigma_positive_fraction": out_occ, "basis_dim": K, "depth": depth, "reso": reso, "image": [H, W], "step_size": a.step, "cams": a.cams}
+    SCENE.clear()
+    SCENE.update(basis_dim=K, reso=reso, image=[H, W], cams=a.cams, step_size=float(a.step), hard=bool(a.hard))
 
     opts = oops.render_opts(a.step)
     wt = torch.zeros(reso ** 3, device=dev)
@@ -162,6 +190,8 @@ def measure(a):
     out["tree_build_ms"] = timed(lambda: oops.tree_from_mask(mask, depth), reps=3)
     tree.refine_from_mask(mask)
     out["n_internal"], out["level_nodes"] = tree.n_internal, tree.level_nodes
+    out["tree_data_MB"] = tree.data.numel() * 4 / 1e6
+    SCENE.update(n_internal=int(tree.n_internal), tree_data_MB=float(out["tree_data_MB"]))      # the tree depends on the camera set
     node0, count = tree.max_depth_nodes()
     out["sample_cells_ms"] = timed(lambda: tree.sample_max_depth_cells(8, seed=1), reps=3)
     out["sample_points"] = count * 8 * 8
@@ -221,9 +251,9 @@ def measure(a):
                                               dict(avg, marches=marches), "octree_render_bwd4_kernel" if reuse else None)
     out["grad_abs_sum"] = float(grad.double().abs().sum())
     out["sgd_ms"] = timed(lambda: oops.sgd_step(tree.data, grad, 0.0), reps=3)
-    out["tree_data_MB"] = tree.data.numel() * 4 / 1e6
     # SGD streams data + gradient in and data out: 12 B per float
     out["sgd_roofline"] = roofline(tree.data.numel() * 12.0, tree.data.numel() * 12.0, out["sgd_ms"], {}, "sgd_kernel")
+    out["scene"] = dict(SCENE)
     return out
 
 

@@ -26,6 +26,18 @@ def pmc(path, counter):
 
 
 def main(src, dst_dir, tag, pmc_cams=2):
+    import json
+    # the scene the counter passes ran on (scripts/octree_bench.py prints it; gpu_session.sh keeps each pass's JSON): a ratio of
+    # these bytes to a floor is only meaningful for the SAME tree, cameras and image size -- octree_bench.py checks before dividing
+    scenes = []
+    for name in ("opmc1.json", "opmc2.json"):
+        try:
+            with open(os.path.join(src, name)) as f:
+                scenes.append(json.load(f)["scene"])
+        except Exception:
+            pass
+    if len(scenes) == 2 and scenes[0] != scenes[1]:
+        raise SystemExit(f"the two counter passes ran on different scenes: {scenes}")
     stats = {}
     ks = os.path.join(src, "oprof", "obench_kernel_stats.csv")
     with open(ks) as f:
@@ -47,9 +59,11 @@ def main(src, dst_dir, tag, pmc_cams=2):
         g.write("\n".join(out) + "\n")
     print("\n".join(out))
     # machine-readable twin for bench.py's `octree` record (scripts/octree_bench.py hbm_traffic): short kernel name -> bytes
-    import json
     import subprocess
-    doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py, session {tag}", "kernels": {}}
+    doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/octree_bench.py, session {tag}", "kernels": {},
+           "scene": scenes[0] if scenes else {}}
+    if scenes:
+        pmc_cams = int(scenes[0].get("cams", pmc_cams))
     try:
         doc["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)),
                                                 stderr=subprocess.DEVNULL).decode().strip()

@@ -1192,6 +1192,30 @@ def _one_train_step(ops, dev, cfg, flat, B, skip, seed=3):
     return grads.cpu(), stats.cpu(), live, total
 
 
+@pytest.mark.parametrize("B,wd", [(512, 0.0), (2500, 0.05)])
+def test_coarse_reverse_side_stream_is_bit_identical(B, wd):
+    """PXO_TUNE_COARSE_REVERSE_STREAM: the coarse level's reverse pass on the library's side stream (beside the fine forward)
+    or on the caller's stream -- the same kernels with the same inputs, so not a bit may change, step after step on ONE
+    workspace (the slabs of the weight-gradient GEMMs are shared by the two levels: the join is what keeps them apart), dense and
+    skipping, with weight decay (an axpy on the forked half) and with a NaN-poisoned workspace."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sparsity_npoints=777, weight_decay_mult=wd)
+    flat = make_params(cfg)
+    default = ops.get_tuning(ops.TUNE_COARSE_REVERSE_STREAM)
+    assert default == 0
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.set_tuning(ops.TUNE_COARSE_REVERSE_STREAM, mode)
+            assert ops.get_tuning(ops.TUNE_COARSE_REVERSE_STREAM) == mode
+            res[mode] = [_one_train_step(ops, dev, cfg, flat, B, skip, seed=3 + rep)[:2] for skip in (0, 1) for rep in range(2)]
+    finally:
+        ops.set_tuning(ops.TUNE_COARSE_REVERSE_STREAM, default)
+    for (g0, s0), (g1, s1) in zip(res[0], res[1]):
+        assert bool(torch.isfinite(g1).all())
+        assert torch.equal(g0, g1) and torch.equal(s0, s1)
+
+
 @pytest.mark.parametrize("B", [600, 2500])
 def test_tile_counter_schedule_is_bit_identical(B):
     """PXO_TUNE_TILE_SCHED: the persistent workgroups of the dense training kernels take their tiles from a device counter

@@ -551,22 +551,14 @@ __device__ __forceinline__ void fwd_subtile_x6(__bf16* __restrict__ planes, cons
     const float* hb = bias + 8 * kW;
     const int col0 = (RGB ? 0 : NHB - 1) * 32;           // head column of the first staged column
     if (RGB) {
-      // thread = (column lane & 63 of a 64-column block, row tid >> 6 + 8 i): a wave writes the <= 64 contiguous floats of one row
-      // (no division by the run-time C in the loop)
+      const int n_out = (int)rows * C;
       float* dst = raw_rgb + row0 * C;
-      const int c6 = tid & 63, r8 = tid >> 6;
-      for (int cb2 = 0; cb2 * 64 < C; ++cb2) {
-        const int col = cb2 * 64 + c6;
-        if (col >= C) continue;
-        const float bcol = hb[col];
+      for (int o = tid; o < n_out; o += kYThreads) {
+        const int row = o / C, col = o - row * C;
+        float v = red[row * RS + col];
 #pragma unroll
-        for (int i = 0; i < kYRows / kYWaves; ++i) {
-          const int row = r8 + kYWaves * i;
-          float v = red[row * RS + col];
-#pragma unroll
-          for (int k = 1; k < NS; ++k) v += red[(k * kYRows + row) * RS + col];
-          if (row < rows) dst[row * C + col] = v + bcol;
-        }
+        for (int k = 1; k < NS; ++k) v += red[(k * kYRows + row) * RS + col];
+        dst[o] = v + hb[col];
       }
     }
     if (tid < rows) {                                    // sigma: head column C

@@ -43,6 +43,7 @@ FLOP_RENDER_PER_RAY = {3: 257.8e6, 4: 261.4e6}
 FLOP_SIGMA_PER_POINT = 982528                        # trunk + sigma head only (131.9 TFLOP at 512^3)
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 ALL_EXTRAS = ("converge", "strong512", "render_fwd", "grid512", "octree", "bf16x3", "bf16x6", "coarse64", "tt_sh25")
+OPT_IN_EXTRAS = ("bf16x6_converge",)      # accepted by --extras, not in the default line
 
 
 def parse(argv=None):
@@ -55,7 +56,7 @@ def parse(argv=None):
     p.add_argument("--preset", choices=["blender", "tt"], default="blender")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="headline only")
-    p.add_argument("--extras", default=",".join(ALL_EXTRAS), help="comma-separated subset of " + ",".join(ALL_EXTRAS))
+    p.add_argument("--extras", default=",".join(ALL_EXTRAS), help="comma-separated subset of " + ",".join(ALL_EXTRAS + OPT_IN_EXTRAS))
     p.add_argument("--force-dist", action="store_true",
                    help="initialise RCCL and issue the per-step collectives even with one rank (exercises the "
                         "multi-GPU code path on a 1-GPU box)")
@@ -73,7 +74,7 @@ def parse(argv=None):
     p.add_argument("--no-cpu-full", action="store_true",
                    help="leave the B = 4096 shape (configs[1], ~3 minutes of CPU) out of the CPU baseline; `value` is then the B = --cpu-rays figure")
     p.add_argument("--cpu-full", action="store_true", help="(default since round 6; kept for old command lines)")
-    p.add_argument("--cpu-budget-s", type=float, default=600.0,
+    p.add_argument("--cpu-budget-s", type=float, default=330.0,
                    help="wall-clock cap of the whole CPU baseline: a shape that would exceed it stops early and reports timed_steps < requested")
     p.add_argument("--converge-steps", type=int, default=2000, help="training budget of the `converge` record")
     p.add_argument("--converge-views", type=int, default=2, help="held-out 800x800 views rendered for eval PSNR")
@@ -135,7 +136,8 @@ def cpu_baseline(a, args_ns, device):
     configs[1]'s B = 4096 (the headline's shape, ~3 minutes of CPU; --no-cpu-full leaves it out).  `value` is the B = 4096,
     64 + 128 figure (the B = 1024 one without it).  Thread count: torch's intra-op pool oversubscribes badly on many-core
     hosts, so a 32-ray probe picks among a few candidates; BASELINE.md section 3 says `nproc`, so the 64 + 128 shape at B = 1024
-    is ALSO timed with every hardware thread (1 warm-up + 3 timed steps) and reported next to the probed-best figure.  The whole
+    is ALSO timed with every hardware thread (ONE step, no warm-up: 85 s on a 256-thread host, where start-up effects are noise)
+    and reported next to the probed-best figure.  The whole
     leg is capped at --cpu-budget-s: a shape that runs out of budget stops early and says so (timed_steps < requested)."""
     import platform
     from oracle import nerf_oracle as O
@@ -211,7 +213,7 @@ def cpu_baseline(a, args_ns, device):
         shapes.append(protocol(4096, True))
     else:
         dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: left out by --no-cpu-full)")
-    all_threads = protocol(a.cpu_rays, True, warm=1, timed=3, threads=ncpu) if ncpu != cores else dict(shapes[1])
+    all_threads = protocol(a.cpu_rays, True, warm=0, timed=1, threads=ncpu) if ncpu != cores else dict(shapes[1])
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -404,16 +406,10 @@ def x6_state_twin(tr):
     return models.NerfModel(cfg), st
 
 
-def run_converge(job, a):
-    """The second half of BASELINE.json's metric: eval PSNR.  A fixed training budget from the fixed-seed initialisation
-    (`--converge-steps` steps of `--batch` rays per GPU, the headline's step), then render_image of held-out views of the
-    TEST split with deterministic sampling (nerf_sh/eval.py:57, nerf_sh/train.py:245-268, utils.py:331-381) and
-    compute_psnr (utils.py:384-393) against their ground truth."""
+def eval_views(job, a, tr):
+    """render_image of `--converge-views` held-out views of the TEST split at tr's current parameters, deterministic sampling;
+    -> ([psnr per view], seconds (max over ranks), the test set)."""
     from plenoctree_amd.nerf_sh.nerf import datasets, utils
-    job.sync()
-    t0 = time.perf_counter()
-    tr = run_train(job, a.preset, a.converge_steps, 0, events=False)
-    t_train = tr["elapsed"]
     test = datasets.Synthetic("test", tr["args"], job.device)
     model, state = tr["model"], tr["state"]
     comm = job.comm()
@@ -427,7 +423,21 @@ def run_converge(job, a):
                                        world_size=job.world, rank=job.rank, gather=comm.all_gather_cat)
         psnrs.append(utils.compute_psnr(((rgb - ex["pixels"]) ** 2).mean().item()))
     job.sync()
-    t_render = job.max_over_ranks(time.perf_counter() - t1)
+    return psnrs, job.max_over_ranks(time.perf_counter() - t1), test
+
+
+def run_converge(job, a):
+    """The second half of BASELINE.json's metric: eval PSNR.  A fixed training budget from the fixed-seed initialisation
+    (`--converge-steps` steps of `--batch` rays per GPU, the headline's step), then render_image of held-out views of the
+    TEST split with deterministic sampling (nerf_sh/eval.py:57, nerf_sh/train.py:245-268, utils.py:331-381) and
+    compute_psnr (utils.py:384-393) against their ground truth."""
+    from plenoctree_amd.nerf_sh.nerf import datasets, utils
+    job.sync()
+    t0 = time.perf_counter()
+    tr = run_train(job, a.preset, a.converge_steps, 0, events=False)
+    t_train = tr["elapsed"]
+    model, state = tr["model"], tr["state"]
+    psnrs, t_render, test = eval_views(job, a, tr)
     # At this trained state: the same steps with the dense reverse pass and with PxoCfg.skip_zero_rows (sample rows whose
     # upstream gradient is exactly zero -- empty space, occluded samples, background rays -- left out of backward(data) and
     # the weight-gradient GEMMs in 16-row chunks; bit-identical gradients, tests/test_gpu_parity.py).  Not the headline:
@@ -476,11 +486,11 @@ def run_converge(job, a):
             steps6(s0 + 3 + k, 3)
             sparse["bf16x6_skip_zero_rows_rays_per_s"] = steps6(s0 + 6 + k, k)
             m6, s6 = None, None
-    return {"eval_psnr": sum(psnrs) / len(psnrs), "sparse_backward": sparse, "eval_psnr_per_view": psnrs, "views": n_views,
+    return {"eval_psnr": sum(psnrs) / len(psnrs), "sparse_backward": sparse, "eval_psnr_per_view": psnrs, "views": len(psnrs),
             "view_size": [test.h, test.w], "train_steps": a.converge_steps, "rays_per_step": tr["per_gpu"] * job.world,
             "train_s": t_train, "train_rays_per_s": tr["per_gpu"] * job.world * a.converge_steps / t_train,
             "train_psnr_last_batch": tr["stats"]["psnr"], "render_s": t_render,
-            "render_rays_per_s": n_views * test.h * test.w / t_render, "wall_s": time.perf_counter() - t0,
+            "render_rays_per_s": len(psnrs) * test.h * test.w / t_render, "wall_s": time.perf_counter() - t0,
             "data": "synthetic analytic scene (three shaded spheres, white background): 100 train / 200 test poses, "
                     "datasets.Synthetic; seed-fixed initialisation and batches",
             "sampling": "train randomized (Philox), eval deterministic"}
@@ -539,6 +549,17 @@ def run_x6(job, a, f32_head):
                    "as close to float64 as the float32-MFMA kernels and held to every bound of the float32 path "
                    "(tests/test_gpu_x6.py, test_gpu_fullsize.py, test_gpu_trained_state.py, test_gpu_reference_fixtures.py); "
                    "`equivalent_f32_tflops` = the float32 path's algorithmic FLOP over this kernel's time (NOT a bf16 rate)"}
+    if "bf16x6_converge" in a.extras.split(","):
+        # opt-in (not in the default line: +45 s): the `converge` record's run -- the same budget, initialisation, batches and seeds --
+        # trained END TO END in bf16x6, and its eval PSNR on the same held-out views
+        job.sync()
+        t0 = time.perf_counter()
+        tr = run_train(job, a.preset, a.converge_steps, 0, events=False, mlp_precision="bf16x6")
+        psnrs, t_render, _ = eval_views(job, a, tr)
+        rec["converge"] = {"eval_psnr": sum(psnrs) / len(psnrs), "eval_psnr_per_view": psnrs, "train_steps": a.converge_steps,
+                           "rays_per_step": tr["per_gpu"] * job.world, "train_s": tr["elapsed"],
+                           "train_rays_per_s": tr["per_gpu"] * job.world * a.converge_steps / tr["elapsed"],
+                           "train_psnr_last_batch": tr["stats"]["psnr"], "render_s": t_render, "wall_s": time.perf_counter() - t0}
     return rec
 
 
@@ -689,7 +710,7 @@ def main(argv=None):
             tuning[k] = int(v)
 
     want = [] if a.no_extras else [e for e in a.extras.split(",") if e]
-    unknown = [e for e in want if e not in ALL_EXTRAS]
+    unknown = [e for e in want if e not in ALL_EXTRAS + OPT_IN_EXTRAS]
     if unknown:
         raise SystemExit(f"bench.py --extras: unknown record(s) {unknown}")
     need_snapshot = any(e in want for e in ("render_fwd", "grid512", "bf16x3"))

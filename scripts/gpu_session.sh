@@ -65,8 +65,9 @@ for stage in ${STAGES:-tests bench}; do
     timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
     tail -3 gpurun_out/smoke.log ;;
   bench)
+    t0=$SECONDS
     timeout ${BENCH_TIMEOUT:-1200} python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err
-    echo "bench exit $?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
+    echo "bench exit $? wall $((SECONDS - t0)) s" | tee gpurun_out/bench_wall.txt; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
   prof)
     cd /tmp
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 $PROF_HEAD_ARGS ${PROF_ARGS:-} > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"

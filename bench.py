@@ -129,7 +129,7 @@ def flags_for(a, preset, batch, **over):
     return args
 
 
-def cpu_baseline(a, args_ns, device):
+def cpu_baseline(a, args_ns, device, long_legs=True):
     """The oracle (CPU restatement of the reference graph, not JAX) timed on this host's cores by BASELINE.md section 3's protocol:
     3 warm-up + 10 timed train steps (forward + backward + Adam, float32), rays/s = B x steps/s (nerf_sh/train.py:224), at
     configs[0]'s shapes -- B = 1024 with 64 coarse samples only and with 64 + 128 samples (+ 10k sparsity points) -- and at
@@ -209,20 +209,27 @@ def cpu_baseline(a, args_ns, device):
 
     shapes = [protocol(a.cpu_rays, False), protocol(a.cpu_rays, True)]
     dropped = []
-    if not a.no_cpu_full:
+    full = long_legs and not a.no_cpu_full
+    if full:
         shapes.append(protocol(4096, True))
     else:
-        dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: left out by --no-cpu-full)")
-    all_threads = protocol(a.cpu_rays, True, warm=0, timed=1, threads=ncpu) if ncpu != cores else dict(shapes[1])
+        dropped.append("B=4096, 64+128 (configs[1]; ~3 min of CPU: left out " + ("by --no-cpu-full)" if long_legs else "at N > 1, see the N = 1 line)"))
+    if long_legs and ncpu != cores:
+        all_threads = protocol(a.cpu_rays, True, warm=0, timed=1, threads=ncpu)
+    else:
+        all_threads = dict(shapes[1])
+        if ncpu != cores:
+            all_threads["rays_per_s"] = None
+            dropped.append("the nproc-thread step (left out at N > 1, see the N = 1 line)")
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    head = shapes[-1] if not a.no_cpu_full else shapes[1]
+    head = shapes[-1] if full else shapes[1]
     return {"value": head["rays_per_s"], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "nproc": ncpu, "nproc_threads": {"rays_per_s": all_threads["rays_per_s"], "threads": ncpu, "rays_per_step": all_threads["rays_per_step"],
+            "nproc": ncpu, "nproc_threads": {"rays_per_s": all_threads["rays_per_s"], "threads": ncpu if long_legs else all_threads["threads"], "rays_per_step": all_threads["rays_per_step"],
                                              "timed_steps": all_threads["timed_steps"],
                                              "note": "BASELINE.md section 3 says nproc threads: the same 64+128 shape with every hardware thread"}, "cpu_model": cpu_model or platform.processor(), "torch_version": torch.__version__,
             "threads_probed": cores, "protocol": f"BASELINE.md section 3: {a.cpu_warmup} warm-up + {a.cpu_steps} timed train steps, rays/s = B x steps/s",
@@ -759,10 +766,12 @@ def main(argv=None):
     if "converge" in want:
         extras["converge"] = run_converge(job, a)
 
-    # the CPU baseline is timed on rank 0's host cores only, whatever the world size (the other ranks wait at the barrier)
+    # the CPU baseline is timed on rank 0's host cores.  Its long legs (B = 4096, every hardware thread: ~4 of its 5 minutes
+    # since round 6) run at N = 1 only: at N > 1 the other ranks sit in the closing barrier's collective meanwhile, next to its
+    # watchdog, so they get the two B = 1024 shapes (~1 minute, as in round 5) and the line says which were left out
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a, head["args"], job.device)
+        cpu = cpu_baseline(a, head["args"], job.device, long_legs=world == 1)
     if rank == 0:
         per_gpu, deg, kernels = head["per_gpu"], head["deg"], head["kernels"]
         elapsed = head["elapsed"]

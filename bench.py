@@ -570,11 +570,11 @@ def run_x6(job, a, f32_head):
     return rec
 
 
-def split_precision_twin(tr):
-    """Model/state pair with the same parameters and PxoCfg.mlp_precision = bf16x3 (opt-in inference path)."""
+def split_precision_twin(tr, precision=1):
+    """Model/state pair with the same parameters and PxoCfg.mlp_precision = bf16x3 (1, opt-in inference path) or bf16x6 (2)."""
     from plenoctree_amd.nerf_sh.nerf import models
     cfg = type(tr["model"].cfg).from_buffer_copy(tr["model"].cfg)
-    cfg.mlp_precision = 1
+    cfg.mlp_precision = precision
     twin = dict(tr)
     twin["model"] = models.NerfModel(cfg)
     twin["eval_state"] = models.TrainState(cfg, tr["eval_state"].params.clone())
@@ -720,7 +720,7 @@ def main(argv=None):
     unknown = [e for e in want if e not in ALL_EXTRAS + OPT_IN_EXTRAS]
     if unknown:
         raise SystemExit(f"bench.py --extras: unknown record(s) {unknown}")
-    need_snapshot = any(e in want for e in ("render_fwd", "grid512", "bf16x3"))
+    need_snapshot = any(e in want for e in ("render_fwd", "grid512", "bf16x3", "bf16x6"))
     tr = run_train(job, a.preset, a.steps, a.warmup, snapshot_step=a.eval_step if need_snapshot else None)
     extras = {}
     if "strong512" in want:
@@ -733,6 +733,14 @@ def main(argv=None):
         extras["octree"] = run_octree(job, a)
     if "bf16x6" in want and job.cuda:
         extras["opt_in_bf16x6_training"] = run_x6(job, a, tr["per_gpu"] * world * a.steps / tr["elapsed"])
+        if job.cuda:
+            # the forward-only entry points in the same precision: eval rendering and the 512^3 sigma grid
+            twin = split_precision_twin(tr, 2)
+            r6, g6 = run_render(job, twin), run_grid(job, twin, stages_after_grid=False)
+            extras["opt_in_bf16x6_training"]["inference"] = {
+                "render_fwd_rays_per_s": r6["value"], "render_fwd_ms_per_call": r6["ms_per_call"],
+                "grid512_ms": g6["grid_ms"], "grid512_equivalent_f32_tflops": g6["equivalent_f32_tflops"]}
+            twin = None
     if "bf16x3" in want:
         # opt-in inference precision (NOT the headline, NOT used in training): products as 3 bf16 MFMAs, f32 accumulate
         twin = split_precision_twin(tr)

@@ -80,9 +80,10 @@ typedef struct PxoCfg {
  * PXO_MLP_BF16X6: float32-ACCURATE split precision for the whole path, training included (csrc/mlp_x6_kernels.hip): every
  * float32 operand of the fused MLP forward and backward(data) is split exactly into three bf16 parts and a product is the six
  * partial products of order <= 2^-16 with float32 accumulation (6/16 of the float32 MFMA time; per GEMM at least as close to
- * the float64 product as the float32 MFMA kernels, tests/test_gpu_x6.py).  Saved tensors, gradients and the weight-gradient
- * GEMMs stay float32; pxo_packed_sizes / pxo_pack_weights then describe / write the three-part images (1.5 x the size), both
- * directions.  Opt-in: the headline throughput and every roofline figure of bench.py are PXO_MLP_F32. */
+ * the float64 product as the float32 MFMA kernels, tests/test_gpu_x6.py).  The 256 x 256 weight-gradient products take their
+ * float32 operands through the same split (csrc/wgrad_x6_kernels.hip; PXO_TUNE_X6_WGRAD = 0 keeps them on the float32 pipe);
+ * saved tensors, gradients and every other kernel stay float32; pxo_packed_sizes / pxo_pack_weights then describe / write the
+ * three-part images (1.5 x the size), both directions.  Opt-in: the headline throughput and every roofline figure of bench.py are PXO_MLP_F32. */
 #define PXO_MLP_F32 0
 #define PXO_MLP_BF16X3 1
 #define PXO_MLP_BF16X6 2
@@ -341,6 +342,9 @@ int pxo_grid_sigma(const PxoCfg* cfg, const float* packed_fwd, int reso, int x0,
  *                          level's forward and joins the caller's stream before the fine weight gradients; `grads0_ready` is
  *                          then recorded on that side stream.  Bits unchanged; +0.2 % / +0.7 % at 512 / 4096 rays (r06b). */
 #define PXO_TUNE_COARSE_REVERSE_STREAM 3
+/*   PXO_TUNE_X6_WGRAD      with PXO_MLP_BF16X6 only.  1 (default): the 256x256 weight-gradient products of Dense_1..7 run in bf16x6
+ *                          too (wgrad_x6_kernels.hip); 0: on the float32 MFMA pipe like the float32 path (A/B). */
+#define PXO_TUNE_X6_WGRAD 4
 int pxo_set_tuning(int knob, int value);
 int pxo_get_tuning(int knob, int* value);
 

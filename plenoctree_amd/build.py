@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplenoctree_hip.so")
-SOURCES = ["pxo_api.hip", "mlp_kernels.hip", "mlp_x3_kernels.hip", "mlp_x6_kernels.hip", "wgrad_kernels.hip", "render_kernels.hip", "optim_kernels.hip",
+SOURCES = ["pxo_api.hip", "mlp_kernels.hip", "mlp_x3_kernels.hip", "mlp_x6_kernels.hip", "wgrad_kernels.hip", "wgrad_x6_kernels.hip", "render_kernels.hip", "optim_kernels.hip",
            "octree_kernels.hip"]
 # per-source flags: the octree marchers are compiled without fused contraction (see the file header)
 SOURCE_FLAGS = {"octree_kernels.hip": ["-ffp-contract=off"]}

@@ -24,12 +24,9 @@
 // sample per register quad, so the epilogue writes one ds_write_b64 per plane and one 16-byte global store per quad.
 // Every wave owns 64 rows x 32 features: per 16-deep k-group 6 ds_read_b128 + 3 buffer_load_b128 feed 12 MFMAs.
 #include "pxo_common.h"
+#include "pxo_x6.h"
 
 namespace pxo {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kYRows = 64;                   // rows of a sub-tile
 constexpr int kYRB = kYRows / 32;            // row blocks (all owned by every wave)
@@ -38,36 +35,6 @@ constexpr int kYWaves = kYThreads / 64;      // 8: wave w owns features [32 w, 3
 constexpr int kLDB = 264;                    // LDS row stride in bf16 (256 + 8: conflict-free ds_read_b128)
 constexpr int kPlane = kYRows * kLDB;        // bf16 elements per plane
 static_assert(kYWaves * 32 == kW, "one 32-feature block per wave");
-
-// ------------------------------------------------------------------------------------------
-// exact three-way split
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  const float r = x - (float)a;
-  b = (__bf16)r;
-  c = (__bf16)(r - (float)b);
-}
-// the same for a pair, packed [lo half = first | hi half = second]: v_cvt_pk_bf16_f32, widened back with a shift / a mask
-// (the residuals as 2-vectors: v_pk_add_f32, one instruction per pair)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(f32x2 x) {
-  const bf16x2 h = {(__bf16)x[0], (__bf16)x[1]};
-  uint32_t b;
-  __builtin_memcpy(&b, &h, 4);
-  asm volatile("" : "+v"(b));     // ONE v_cvt_pk_bf16_f32: without this the low half is converted a second time for `b << 16`
-  return b;
-}
-__device__ __forceinline__ f32x2 widen_pk_bf16(uint32_t b) { return f32x2{__uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)}; }
-__device__ __forceinline__ void split3_pair(f32x2 x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  p1 = cvt_pk_bf16(x);
-  const f32x2 r = x - widen_pk_bf16(p1);
-  p2 = cvt_pk_bf16(r);
-  p3 = cvt_pk_bf16(r - widen_pk_bf16(p2));
-}
-__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  split3_pair(f32x2{a, b}, p1, p2, p3);
-}
 
 // ------------------------------------------------------------------------------------------
 // weight packing

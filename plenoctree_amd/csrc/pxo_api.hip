@@ -54,6 +54,7 @@ int num_cus() {
 static std::atomic<int> g_tune_tile_sched{1};
 static std::atomic<int> g_tune_wgrad_ranges{0};
 static std::atomic<int> g_tune_wgrad_skinny_ranges{0};
+static std::atomic<int> g_tune_x6_wgrad{1};
 // PXO_TUNE_COARSE_REVERSE_STREAM: 1 = the reverse pass of the coarse level (backward(data), weight gradients, slab reduce of
 // MLP_0) runs on an internal side stream beside the fine level's forward, whose ragged last round of tiles leaves CUs idle
 // (3.3 rounds at 512 rays per GPU); 0 (default) = everything on the caller's stream.  Same kernels, same sums: bits unchanged.
@@ -86,6 +87,7 @@ static std::unordered_map<const void*, bool> g_step_skipped;
 int tune_tile_sched() { return g_tune_tile_sched; }
 int tune_wgrad_ranges() { return g_tune_wgrad_ranges; }
 int tune_wgrad_skinny_ranges() { return g_tune_wgrad_skinny_ranges; }
+int tune_x6_wgrad() { return g_tune_x6_wgrad; }
 
 int validate_cfg(const PxoCfg* cfg) {
   PXO_REQUIRE(cfg != nullptr, "cfg is NULL");
@@ -317,6 +319,10 @@ int pxo_set_tuning(int knob, int value) {
                   2 * num_cus(), value);
       g_tune_wgrad_skinny_ranges = value;
       return PXO_OK;
+    case PXO_TUNE_X6_WGRAD:
+      PXO_REQUIRE(value == 0 || value == 1, "pxo_set_tuning: bf16x6 weight gradients must be 0 (float32 MFMA) or 1 (bf16x6), got %d", value);
+      g_tune_x6_wgrad = value;
+      return PXO_OK;
     default:
       set_error("pxo_set_tuning: unknown knob %d", knob);
       return PXO_ERR_ARG;
@@ -329,6 +335,7 @@ int pxo_get_tuning(int knob, int* value) {
     case PXO_TUNE_WGRAD_RANGES: *value = g_tune_wgrad_ranges; return PXO_OK;
     case PXO_TUNE_WGRAD_SKINNY_RANGES: *value = g_tune_wgrad_skinny_ranges; return PXO_OK;
     case PXO_TUNE_COARSE_REVERSE_STREAM: *value = g_tune_coarse_stream; return PXO_OK;
+    case PXO_TUNE_X6_WGRAD: *value = g_tune_x6_wgrad; return PXO_OK;
     default: set_error("pxo_get_tuning: unknown knob %d", knob); return PXO_ERR_ARG;
   }
 }

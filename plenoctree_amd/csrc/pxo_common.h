@@ -191,9 +191,13 @@ int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float*
 int tune_tile_sched();        // PXO_TUNE_TILE_SCHED: 0 static stride, 1 device counter (dense training kernels)
 int tune_wgrad_ranges();      // PXO_TUNE_WGRAD_RANGES: 0 = built-in choice, n > 0 = row ranges per layer of the 256x256 products
 int tune_wgrad_skinny_ranges();  // PXO_TUNE_WGRAD_SKINNY_RANGES: the same for the enc-based pair and the head product
+int tune_x6_wgrad();          // PXO_TUNE_X6_WGRAD: 1 (default) = in bf16x6 the 256x256 weight gradients run on the bf16 pipe too, 0 = float32 MFMA
 // can the weight-gradient kernels skip dead chunks for a pass of M rows (every row range fits a workgroup's live list)?
 // If not the whole reverse pass of the step runs dense (pxo_train_fwd_bwd decides up front).
 bool wgrad_skip_supported(int64_t M);
+// wgrad_x6_kernels.hip: the 256x256 products of Dense_1..7 in bf16x6 (same grid, slabs and reduce as the float32 launch)
+void launch_wgrad_main_x6(const float* acts, const float* dz1, int64_t M, int64_t rpw, int P, float* slab, int n_layers,
+                          int64_t layer_stride, const uint8_t* chunk_live, hipStream_t s);
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,

@@ -492,7 +492,9 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   enc_pair(slab_enc);
   {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
-    if (chunk_live)
+    if (cfg->mlp_precision == PXO_MLP_BF16X6 && tune_x6_wgrad() != 0)
+      launch_wgrad_main_x6(acts, dz + MW, M, rpwb, Pb, slab_main, NL, MW, chunk_live, s);
+    else if (chunk_live)
       hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2, false, 0, true>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256),
                          0, s, acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW, chunk_live);
     else

@@ -354,7 +354,7 @@ def grid_sigma(cfg, packed_fwd, reso, x0, x1, offset, scale, out=None):
 PROF_MLP_FWD, PROF_MLP_BWD_DATA, PROF_WGRAD_MAIN, PROF_WGRAD_OTHER, PROF_NUM_TAGS = 0, 1, 2, 3, 4
 
 
-TUNE_TILE_SCHED, TUNE_WGRAD_RANGES, TUNE_WGRAD_SKINNY_RANGES, TUNE_COARSE_REVERSE_STREAM = 0, 1, 2, 3        # PXO_TUNE_* of include/plenoctree_hip.h
+TUNE_TILE_SCHED, TUNE_WGRAD_RANGES, TUNE_WGRAD_SKINNY_RANGES, TUNE_COARSE_REVERSE_STREAM, TUNE_X6_WGRAD = 0, 1, 2, 3, 4        # PXO_TUNE_* of include/plenoctree_hip.h
 
 
 def set_tuning(knob, value):

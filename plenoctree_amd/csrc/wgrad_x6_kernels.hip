@@ -3,14 +3,16 @@
 // split precision of mlp_x6_kernels.hip (PxoCfg.mlp_precision = PXO_MLP_BF16X6): every float32 operand x = x1 + x2 + x3
 // exactly (bf16 each), a product = the six partial products of order <= 2^-16 on v_mfma_f32_32x32x16_bf16, float32 accumulation.
 //
-// Same decomposition as wgrad_kernel<256, 256, 2, 2, ..., NSPLIT = 2>: split-K over row ranges, two 4-wave workgroups per
-// range (column halves, partners on one XCD), 16-row chunks (= one live flag of the zero-row skipping pass) double-buffered
-// in LDS, one slab per range, the SAME slabs / reduce / grid mapping, so the launcher swaps one launch for the other.
-// What differs is the staging: float32 rows come from HBM, are split in registers and land in LDS as bf16 planes with the
-// CONTRACTION index (the row) contiguous -- [part][k-block of 8 rows][column] x 16 bytes -- which is what both MFMA operands
-// of a "TN" product want: a lane's A fragment is 8 rows of one input feature, its B fragment 8 rows of one output column.
-// A thread owns one column of the chunk (16 dword loads, lanes along the row: 256-byte wave loads), so its 8-row groups are
-// whole fragments: one ds_write_b128 per (part, k-block), conflict-free both ways.
+// Split-K over the row ranges of wgrad_kernel<256, 256, ...> (same ranges, same slabs, same fixed-order reduce, same live-chunk
+// walk in the zero-row skipping pass), but ONE 8-wave workgroup per range computes the whole 256 x 256 product (wave tile
+// 128 x 64: 8 accumulator blocks), so every operand element is split once.  16-row chunks (= one live flag, = the K of one
+// MFMA) double-buffered in LDS.  What differs from the float32 kernel is the staging: float32 rows come from HBM, are split in
+// registers and land in LDS as bf16 planes with the CONTRACTION index (the row) contiguous -- [part][k-block of 8 rows][column]
+// x 16 bytes -- which is what both MFMA operands of a "TN" product want: a lane's A fragment is 8 rows of one input feature,
+// its B fragment 8 rows of one output column.  A thread owns (one column, one k-block) of X and of dZ: 8 + 8 dword loads with
+// the lanes along the row (256-byte wave loads), each group of 8 a whole fragment: one ds_write_b128 per part, conflict-free
+// both ways.  (A first version with two 4-wave workgroups per range -- column halves, X split twice -- gave the same bits
+// and was 7 % slower: 2.63 vs 2.44 ms per launch.)
 #include "pxo_common.h"
 #include "pxo_x6.h"
 
@@ -18,8 +20,7 @@ namespace pxo {
 
 namespace {
 constexpr int kGK = kLiveRows;             // 16 rows per chunk = the K of one MFMA
-constexpr int kGThreads = 256;
-constexpr int kGHalf = kW / 2;             // output columns of a workgroup
+constexpr int kGThreads = 512;
 constexpr int kGMaxLive = 2048;            // as wgrad_kernels.hip: live-chunk list of a sparse workgroup
 static_assert(kGK == 16, "one v_mfma_f32_32x32x16_bf16 per chunk and block");
 }  // namespace
@@ -28,52 +29,44 @@ template <bool SPARSE>
 __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, int64_t M, int64_t rows_per_wg, int P,
     float* __restrict__ slab, int n_layers, int64_t layer_stride, const uint8_t* __restrict__ chunk_live) {
-  // [buffer][part][k-block][column] fragments of 8 bf16
   __shared__ __attribute__((aligned(16))) bf16x8 xs[2][3][2][kW];
-  __shared__ __attribute__((aligned(16))) bf16x8 zs[2][3][2][kGHalf];
+  __shared__ __attribute__((aligned(16))) bf16x8 zs[2][3][2][kW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;            // wave tile: input features [128 wr, +128) x columns [64 wc, +64) of the half
-  int bid = blockIdx.x;
+  const int wr = wave >> 2, wc = wave & 3;            // wave tile: input features [128 wr, +128) x output columns [64 wc, +64)
+  int p = blockIdx.x;
   {
-    const int per = gridDim.x / n_layers, g = bid / per;
-    bid -= g * per;
+    const int per = gridDim.x / n_layers, g = p / per;
+    p -= g * per;
     X += (int64_t)g * layer_stride;
     dZ += (int64_t)g * layer_stride;
     slab += (int64_t)g * P * kW * kW;
   }
-  const int grp = bid / 16, r16 = bid % 16;
-  const int p = grp * 8 + (r16 & 7), half = r16 >> 3;
   if (p >= P) return;
-  const int ncol0 = half * kGHalf;
   const int64_t r_begin = (int64_t)p * rows_per_wg;
   int64_t r_end = r_begin + rows_per_wg;
   if (r_end > M) r_end = M;
   const int nchunks = (int)((r_end - r_begin + kGK - 1) / kGK);
   const int64_t range_rows = r_end - r_begin;
-
-  // buffer loads on the workgroup's own row range: rows past its end read as zeros by the bounds check (wgrad_kernels.hip)
   const __amdgpu_buffer_rsrc_t rsX =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + r_begin * kW), 0, (int)(range_rows * kW * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(dZ + r_begin * kW + ncol0), 0, (int)((range_rows * kW - ncol0) * 4), 0x00020000);
-  // X: thread = input feature tid, 16 rows; dZ: thread = (column tid & 127, k-block tid >> 7), 8 rows
-  const uint32_t xvo = (uint32_t)tid * 4u;
-  const int zc = tid & (kGHalf - 1), zkb = tid >> 7;
-  const uint32_t zvo = (uint32_t)(zkb * 8 * kW + zc) * 4u;
+  const __amdgpu_buffer_rsrc_t rsZ =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dZ + r_begin * kW), 0, (int)(range_rows * kW * 4), 0x00020000);
+  // thread = (column tid & 255, k-block tid >> 8): 8 rows of X and 8 rows of dZ
+  const int sc = tid & (kW - 1), skb = tid >> 8;
+  const uint32_t svo = (uint32_t)(skb * 8 * kW + sc) * 4u;
 
-  struct Stage { float x[kGK]; float z[8]; };
+  struct Stage { float x[8]; float z[8]; };
   auto load_chunk = [&](int ch, Stage& st) {
     const int so = ch * (kGK * kW * 4);
 #pragma unroll
-    for (int r = 0; r < kGK; ++r)
-      st.x[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, xvo, so + r * (kW * 4), 0));
+    for (int r = 0; r < 8; ++r)
+      st.x[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, svo, so + r * (kW * 4), 0));
 #pragma unroll
     for (int r = 0; r < 8; ++r)
-      st.z[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, zvo, so + r * (kW * 4), 0));
+      st.z[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, svo, so + r * (kW * 4), 0));
   };
-  // 8 rows of one column -> the three 16-byte fragments
   struct Frag3 { u32x4 q[3]; };
   auto split8 = [&](const float* v) {
     Frag3 f;
@@ -85,18 +78,9 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     }
     return f;
   };
-  auto put_x = [&](int buf, int kbi, const Frag3& f) {
+  auto put = [&](bf16x8 (*dst)[2][kW], const Frag3& f) {
 #pragma unroll
-    for (int part = 0; part < 3; ++part) xs[buf][part][kbi][tid] = __builtin_bit_cast(bf16x8, f.q[part]);
-  };
-  auto put_z = [&](int buf, const Frag3& f) {
-#pragma unroll
-    for (int part = 0; part < 3; ++part) zs[buf][part][zkb][zc] = __builtin_bit_cast(bf16x8, f.q[part]);
-  };
-  auto store_chunk = [&](int buf, const Stage& st) {
-    put_x(buf, 0, split8(st.x));
-    put_x(buf, 1, split8(st.x + 8));
-    put_z(buf, split8(st.z));
+    for (int part = 0; part < 3; ++part) dst[part][skb][sc] = __builtin_bit_cast(bf16x8, f.q[part]);
   };
 
   constexpr int RB = 4, CB = 2;
@@ -109,12 +93,7 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
       for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
 
   const int kb = lane >> 5, l32 = lane & 31;
-  // One chunk.  The six products of a block go through a chain that starts from ZERO and is added to the block's accumulator
-  // once (16 v_add_f32): every rounding inside the chain is relative to the 16-row partial sum, one rounding per chunk is
-  // relative to the running sum (the float32-MFMA kernel: eight).  Measured on 40,000 rows against float64: 0.62 - 0.76 x the
-  // float32-MFMA kernel's mean error; the chain run on the accumulator itself is 14 % faster and 1.2 - 1.4 x ITS error.
-  // Column-block fragments stay in registers, the four row blocks' fragments stream through.
-  // Branch-free (the last chunk re-loads and re-stores itself into the buffer nobody reads): ONE scheduling region per chunk.
+  // chunk `buf` is multiplied; the loads of chunk + 1 are issued first and split / stored to the other buffer behind the MFMAs
   auto run_chunk = [&](int buf, Stage& st, int ld_ch) {
     load_chunk(ld_ch, st);
     bf16x8 b[CB][3];
@@ -122,14 +101,21 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     for (int c = 0; c < CB; ++c)
 #pragma unroll
       for (int part = 0; part < 3; ++part) b[c][part] = zs[buf][part][kb][(wc * CB + c) * 32 + l32];
-    Frag3 fx0, fx1, fz;
+    bf16x8 an[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) an[part] = xs[buf][part][kb][(wr * RB) * 32 + l32];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       bf16x8 a[3];
 #pragma unroll
-      for (int part = 0; part < 3; ++part) a[part] = xs[buf][part][kb][(wr * RB + r) * 32 + l32];
-      // the leading product FIRST, onto zero; then the corrections onto it (the other order -- the big product last, onto
-      // the small sum -- measured 2.5 x the float32-MFMA kernel's error, this one 0.7 x; EXPERIMENTS, round 6)
+      for (int part = 0; part < 3; ++part) a[part] = an[part];
+      if (r + 1 < RB) {                        // the next row block's fragments are requested before this block's MFMAs
+#pragma unroll
+        for (int part = 0; part < 3; ++part) an[part] = xs[buf][part][kb][(wr * RB + r + 1) * 32 + l32];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the leading product FIRST, onto zero; then the corrections onto it (the other order -- the big product last, onto the
+      // small sum -- measured 2.5 x the float32-MFMA kernel's error, this one 0.7 x; EXPERIMENTS, round 6)
       constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 t[CB];
@@ -139,21 +125,14 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
       for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int c = 0; c < CB; ++c) t[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[k]], b[c][PB[k]], t[c], 0, 0, 0);
-      // the next chunk's split, a third per row block from the second one on (the loads were issued a row block earlier)
-      if (r == 1) fx0 = split8(st.x);
-      if (r == 2) fx1 = split8(st.x + 8);
-      if (r == 3) fz = split8(st.z);
+      if (r == 2) put(xs[buf ^ 1], split8(st.x));
+      if (r == 3) put(zs[buf ^ 1], split8(st.z));
 #pragma unroll
       for (int c = 0; c < CB; ++c) acc[r][c] += t[c];
     }
-    put_x(buf ^ 1, 0, fx0);
-    put_x(buf ^ 1, 1, fx1);
-    put_z(buf ^ 1, fz);
     __syncthreads();
   };
 
-  // zero-row skipping: the live chunks of the range, in order (wgrad_kernels.hip; same accumulation order over the chunks
-  // that contribute => the same bits as the dense walk)
   constexpr int kMaxLive = SPARSE ? kGMaxLive : 1;
   __shared__ uint16_t live_list[kMaxLive];
   __shared__ int live_count;
@@ -183,7 +162,8 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     Stage st;
     if (n_run > 0) {
       load_chunk(chunk_at(0), st);
-      store_chunk(0, st);
+      put(xs[0], split8(st.x));
+      put(zs[0], split8(st.z));
     }
     __syncthreads();
     for (int i = 0; i < n_run; ++i) run_chunk(i & 1, st, chunk_at(i + 1 < n_run ? i + 1 : i));
@@ -194,7 +174,7 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-      const int n = ncol0 + (wc * CB + c) * 32 + l32;
+      const int n = (wc * CB + c) * 32 + l32;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int i = (wr * RB + r) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kb;
@@ -206,7 +186,7 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
 // grid / argument conventions of the float32 launch it replaces (launch_mlp_bwd_weights)
 void launch_wgrad_main_x6(const float* acts, const float* dz1, int64_t M, int64_t rpw, int P, float* slab, int n_layers,
                           int64_t layer_stride, const uint8_t* chunk_live, hipStream_t s) {
-  const dim3 grid(n_layers * ((P + 7) / 8) * 16), block(kGThreads);
+  const dim3 grid(n_layers * P), block(kGThreads);
   if (chunk_live)
     hipLaunchKernelGGL((wgrad_x6_kernel<true>), grid, block, 0, s, acts, dz1, M, rpw, P, slab, n_layers, layer_stride, chunk_live);
   else

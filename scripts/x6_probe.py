@@ -23,11 +23,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--sigma-shift", type=float, default=0.0)
     ap.add_argument("--variants", type=str, default="f32,x6,f32_skip,x6_skip")
+    ap.add_argument("--x6-wgrad", type=int, default=None, help="pxo_set_tuning(PXO_TUNE_X6_WGRAD, n) before the runs (A/B)")
     args = ap.parse_args()
     from plenoctree_amd import ops
     from oracle import nerf_oracle as O           # parameter initialisation of the test helpers only
     from _helpers import make_params, make_rays, pxo_cfg, split_mlp
     dev = torch.device("cuda:0")
+    if args.x6_wgrad is not None:
+        ops.set_tuning(ops.TUNE_X6_WGRAD, args.x6_wgrad)
     cfg = O.Cfg()
     flat = make_params(cfg, bias_scale=0.2)
     n = flat.numel() // 2

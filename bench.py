@@ -542,7 +542,8 @@ def run_coarse64(job, a):
 def run_x6(job, a, f32_head):
     """Opt-in PxoCfg.mlp_precision = bf16x6 (csrc/mlp_x6_kernels.hip): the headline's step with the fused MLP forward (saved
     tensors) and backward(data) evaluated as six bf16 partial products per float32 product, float32 accumulation, everything
-    that leaves the kernels float32, weight-gradient GEMMs native float32.  Same batches, same seeds, dense reverse pass."""
+    that leaves the kernels float32; the 256x256 weight-gradient products take their float32 operands through the same split
+    (csrc/wgrad_x6_kernels.hip), the skinny ones stay on the float32 pipe.  Same batches, same seeds, dense reverse pass."""
     k = max(20, a.steps // 2) if job.cuda else a.steps
     t = run_train(job, a.preset, k, 3 if job.cuda else 1, mlp_precision="bf16x6")
     v = t["per_gpu"] * job.world * k / t["elapsed"]
@@ -553,7 +554,7 @@ def run_x6(job, a, f32_head):
            "final_stats": t["stats"],
            "note": "opt-in, float32-accurate: x = x1 + x2 + x3 exactly (bf16 each), the six products of order <= 2^-16 on "
                    "v_mfma_f32_32x32x16_bf16, leading product and corrections in separate float32 accumulators; per GEMM at least "
-                   "as close to float64 as the float32-MFMA kernels and held to every bound of the float32 path "
+                   "as close to float64 as the float32-MFMA kernels (the 256x256 weight-gradient products included) and held to every bound of the float32 path "
                    "(tests/test_gpu_x6.py, test_gpu_fullsize.py, test_gpu_trained_state.py, test_gpu_reference_fixtures.py); "
                    "`equivalent_f32_tflops` = the float32 path's algorithmic FLOP over this kernel's time (NOT a bf16 rate)"}
     if "bf16x6_converge" in a.extras.split(","):

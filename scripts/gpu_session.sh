@@ -138,6 +138,7 @@ for stage in ${STAGES:-tests bench}; do
   pipeline)
     mkdir -p /tmp/pxo_conv
     printf 'dataset: synthetic\nfactor: 0\nnum_coarse_samples: 64\nnum_fine_samples: 128\nuse_viewdirs: false\nwhite_bkgd: true\nbatch_size: 4096\nsh_deg: 3\nrandomized: true\nmax_steps: %s\nprint_every: 250\nsave_every: %s\nrender_every: 1000\nchunk: 8192\n' ${PIPE_STEPS:-3000} ${PIPE_STEPS:-3000} > /tmp/pxo_conv/cfg.yaml
+    [ -n "${PIPE_YAML_EXTRA:-}" ] && printf "${PIPE_YAML_EXTRA}\n" >> /tmp/pxo_conv/cfg.yaml      # e.g. PIPE_YAML_EXTRA='mlp_precision: bf16x6'
     C="--train_dir /tmp/pxo_conv --config /tmp/pxo_conv/cfg.yaml"
     timeout 400 python -m plenoctree_amd.nerf_sh.train $C > gpurun_out/converge.log 2>&1; echo "train exit $?"
     timeout 200 python -m plenoctree_amd.nerf_sh.eval $C --approx_eval_skip 50 --save_output false >> gpurun_out/converge.log 2>&1; echo "eval exit $?"

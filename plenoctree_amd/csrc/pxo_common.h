@@ -25,6 +25,7 @@ constexpr int kMlpWaves = kMlpThreads / 64;
 constexpr int kMaskWords = (kTM / 32) * (8 / kMlpWaves) * 16 / 32;  // relu-mask words per thread per layer
 constexpr int kMaxMlpGrid = 1024;        // upper bound on persistent workgroups
 constexpr int kLiveRows = 16;            // rows per "live" flag of the zero-row skipping backward (= the wgrad chunk height)
+constexpr int kMaxLiveChunks = 2048;     // live-chunk list of a SPARSE wgrad workgroup (LDS): row ranges of at most 32,768 rows
 
 // ---- derived sizes -----------------------------------------------------------------
 __host__ __device__ inline int sh_dim(int deg) { return (deg + 1) * (deg + 1); }

@@ -14,7 +14,6 @@
 namespace pxo {
 
 constexpr int kKC = 32;           // row granularity of the split (rows_per_wg is a multiple of it)
-constexpr int kMaxLiveChunks = 2048;   // live-chunk list of a SPARSE workgroup (LDS): row ranges of at most 32,768 rows
 
 
 // Geometry: NT threads (WR x WC waves), KCH rows per staged chunk, the NOUT columns split over

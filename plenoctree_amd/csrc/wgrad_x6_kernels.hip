@@ -21,7 +21,6 @@ namespace pxo {
 namespace {
 constexpr int kGK = kLiveRows;             // 16 rows per chunk = the K of one MFMA
 constexpr int kGThreads = 512;
-constexpr int kGMaxLive = 2048;            // as wgrad_kernels.hip: live-chunk list of a sparse workgroup
 static_assert(kGK == 16, "one v_mfma_f32_32x32x16_bf16 per chunk and block");
 }  // namespace
 
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     __syncthreads();
   };
 
-  constexpr int kMaxLive = SPARSE ? kGMaxLive : 1;
+  constexpr int kMaxLive = SPARSE ? kMaxLiveChunks : 1;
   __shared__ uint16_t live_list[kMaxLive];
   __shared__ int live_count;
   const bool sparse = SPARSE && chunk_live != nullptr && nchunks <= kMaxLive;

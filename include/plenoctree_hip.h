@@ -99,7 +99,7 @@ typedef struct PxoLeaf {
 
 /* ABI version of this header: bumped whenever a struct gains a field or an entry point changes meaning (5: PxoCfg has
  * noise_std + skip_zero_rows, pxo_profile_enable takes a tag MASK, pxo_set_tuning / pxo_occupy_cus exist; 6: PXO_MLP_BF16X6,
- * pxo_adam_pack_step serves every precision).  A binding checks
+ * pxo_adam_pack_step serves every precision, PXO_TUNE_COARSE_REVERSE_STREAM / PXO_TUNE_X6_WGRAD).  A binding checks
  * pxo_version() == PXO_ABI_VERSION and pxo_cfg_bytes() == sizeof(PxoCfg) after dlopen (plenoctree_amd/_lib.py does): a
  * caller built against an older header would otherwise pass a short PxoCfg and have its tail read from past the end. */
 #define PXO_ABI_VERSION 6

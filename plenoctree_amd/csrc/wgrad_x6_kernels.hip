@@ -124,8 +124,10 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
       for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int c = 0; c < CB; ++c) t[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[k]], b[c][PB[k]], t[c], 0, 0, 0);
-      if (r == 2) put(xs[buf ^ 1], split8(st.x));
-      if (r == 3) put(zs[buf ^ 1], split8(st.z));
+      // the next chunk's split: X behind the second row block's MFMAs, dZ behind the third's (measured, ms per launch: one block
+      // earlier 2.42 -- the loads have not landed --, one later 2.37, at the end 2.38, this 2.29)
+      if (r == 1) put(xs[buf ^ 1], split8(st.x));
+      if (r == 2) put(zs[buf ^ 1], split8(st.z));
 #pragma unroll
       for (int c = 0; c < CB; ++c) acc[r][c] += t[c];
     }

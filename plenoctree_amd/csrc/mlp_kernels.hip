@@ -935,14 +935,15 @@ int mlp_bwd_partials(int64_t M) {
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
                         float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s,
-                        bool counter_is_zero) {
+                        bool counter_is_zero, int flags) {
   if (M == 0) return PXO_OK;
   if (tile_counter && !counter_is_zero && hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), s) != hipSuccess) {
     set_error("mlp_bwd_data: hipMemsetAsync(tile counter) failed");
     return PXO_ERR_HIP;
   }
   if (cfg->mlp_precision == PXO_MLP_BF16X6)
-    return launch_mlp_bwd_data_x6(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, dz, dbias_partial, chunk_live, tile_counter, s);
+    return launch_mlp_bwd_data_x6(cfg, packed_bwd, d_raw_rgb, d_raw_sigma, mask, M, dz, dbias_partial, chunk_live, tile_counter, s,
+                                  (flags & kBiasFromWgrad) == 0);
   if (cfg->mlp_precision != PXO_MLP_F32) { set_error("mlp_bwd_data: mlp_precision bf16x3 is inference-only"); return PXO_ERR_UNSUPPORTED; }
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(mlp_grid(M)), block(kMlpThreads);

@@ -642,7 +642,7 @@ __device__ __forceinline__ bool bwd_subtile_x6(__bf16* __restrict__ planes, floa
                                                const float* __restrict__ d_raw_rgb, const float* __restrict__ d_raw_sigma,
                                                const uint32_t* __restrict__ mask_sub, int64_t M, int deg, int64_t row0,
                                                float* __restrict__ dz, uint8_t* __restrict__ chunk_live, bool accumulate,
-                                               int tid, int wave) {
+                                               int tid, int wave, bool db_all) {
   constexpr int NH = 32 * NHB;                           // head columns (C rgb + sigma + zero padding)
   constexpr int HK = 4 * ((NHB + 1) / 2);                // k-groups of the head^T GEMM (zero-padded)
   constexpr int NHP = 16 * HK;                           // staged columns
@@ -748,13 +748,16 @@ __device__ __forceinline__ bool bwd_subtile_x6(__bf16* __restrict__ planes, floa
         pc[r][1] = pair_quads(pq[2], pq[3]);
       }
     }
-    // bias gradient of layer l: column sums over the sub-tile's samples (= lanes), fixed order
+    // bias gradient of layer l: column sums over the sub-tile's samples (= lanes), fixed order.  !db_all: Dense_1..7's come
+    // from the weight-gradient kernel, which sums the columns of dz_1..7 while it streams them (pxo_common.h kBiasFromWgrad)
+    if (db_all || l == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float sum = sum_half_wave(cs[i >> 1][i & 1]);
-      if ((lane & 31) == 31) {
-        float* p = dbp + l * kW + 8 * (i >> 2) + (i & 3);
-        *p = accumulate ? *p + sum : sum;
+      for (int i = 0; i < 16; ++i) {
+        const float sum = sum_half_wave(cs[i >> 1][i & 1]);
+        if ((lane & 31) == 31) {
+          float* p = dbp + l * kW + 8 * (i >> 2) + (i & 3);
+          *p = accumulate ? *p + sum : sum;
+        }
       }
     }
     if (l > 0) mw = mask_sub[(int64_t)(l - 1) * (2 * kYThreads) + 2 * tid];     // next layer's mask, fetched under the GEMM
@@ -775,7 +778,7 @@ template <int NHB, bool SKIP, bool DYN>
 __global__ __launch_bounds__(kYThreads, 2) void mlp_bwd_data_x6_kernel(
     const float* __restrict__ pkb, const float* __restrict__ d_raw_rgb, const float* __restrict__ d_raw_sigma,
     const uint32_t* __restrict__ mask, int64_t M, int deg, TileSched ts, float* __restrict__ dz,
-    float* __restrict__ dbias_partial, uint8_t* __restrict__ chunk_live, unsigned int* __restrict__ tile_counter) {
+    float* __restrict__ dbias_partial, uint8_t* __restrict__ chunk_live, unsigned int* __restrict__ tile_counter, int db_all) {
   constexpr int HK = 4 * ((NHB + 1) / 2);
   __shared__ __attribute__((aligned(16))) __bf16 planes[3 * kPlane];
   __shared__ __attribute__((aligned(16))) float stage[kYRows * (16 * HK + 4)];
@@ -793,18 +796,19 @@ __global__ __launch_bounds__(kYThreads, 2) void mlp_bwd_data_x6_kernel(
         const int64_t row0 = slot * kTM + sub * kYRows;
         if (row0 < M)
           any |= bwd_subtile_x6<NHB, SKIP>(planes, stage, db_acc, nz, pkb, d_raw_rgb, d_raw_sigma, mslot + sub, M, deg, row0, dz,
-                                           chunk_live, any, tid, wave);
+                                           chunk_live, any, tid, wave, db_all != 0);
         else if (SKIP && tid < kYRows / kLiveRows)
           chunk_live[row0 / kLiveRows + tid] = 0;
       }
     } else {
       any = bwd_subtile_x6<NHB, SKIP>(planes, stage, db_acc, nz, pkb, d_raw_rgb, d_raw_sigma, mslot, M, deg,
-                                      ts.half_row0 + (slot - ts.n_full) * kYRows, dz, chunk_live, false, tid, wave);
+                                      ts.half_row0 + (slot - ts.n_full) * kYRows, dz, chunk_live, false, tid, wave, db_all != 0);
     }
     if (tid == 0) tile_live[slot] = (uint8_t)(any ? 1 : 0);
     if (any) {       // the slot's bias partial leaves LDS (the last epilogue ended with a barrier)
       float* db = dbias_partial + slot * 9 * kW;
-      for (int i = tid; i < 9 * kW; i += kYThreads) db[i] = db_acc[i];
+      for (int i = tid; i < 9 * kW; i += kYThreads)
+        if (db_all || i < kW || i >= 8 * kW) db[i] = db_acc[i];         // !db_all: rows 1..7 were not computed and are not read
     }
   };
   const int64_t n_slots = ts.n_full + ts.n_half;
@@ -822,14 +826,14 @@ __global__ __launch_bounds__(kYThreads, 2) void mlp_bwd_data_x6_kernel(
 
 int launch_mlp_bwd_data_x6(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
                            const uint32_t* mask, int64_t M, float* dz, float* dbias_partial, uint8_t* chunk_live,
-                           unsigned int* tile_counter, hipStream_t s) {
+                           unsigned int* tile_counter, hipStream_t s, bool db_all) {
   if (M == 0) return PXO_OK;
   KernelTimer timer(PXO_PROF_MLP_BWD_DATA, M, s);
   dim3 grid_dim(x6_grid(M)), block(kYThreads);
   const TileSched ts = tile_sched(M, grid_dim.x);
 #define PXO_X6_BWD_(NHB_, SKIP_, DYN_)                                                                                        \
   hipLaunchKernelGGL((mlp_bwd_data_x6_kernel<NHB_, SKIP_, DYN_>), grid_dim, block, 0, s, packed_bwd, d_raw_rgb, d_raw_sigma, \
-                     mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter)
+                     mask, M, cfg->sh_deg, ts, dz, dbias_partial, chunk_live, tile_counter, db_all ? 1 : 0)
 #define PXO_X6_BWD(NHB_)                                                    \
   do {                                                                      \
     if (chunk_live && tile_counter) PXO_X6_BWD_(NHB_, true, true);          \

@@ -629,6 +629,10 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
   // The coarse reverse pass touches nothing the fine forward reads or writes (its own workspace slices, the MLP_0 half of
   // `grads`; the weight-gradient slabs are shared with the fine pass, which therefore waits for it): with a fine level it runs
   // on the side stream, beside sample_pdf / the fine forward, and joins before the fine weight gradients.
+  // bf16x6 with its own weight-gradient kernel: that kernel also sums the columns of dz_1..7 (the bias gradients of Dense_1..7)
+  // while it streams them, and backward(data) leaves its per-layer lane reductions for those layers out (read ONCE per step: the
+  // two launches of a pass must agree)
+  const int bias_flags = cfg->mlp_precision == PXO_MLP_BF16X6 && tune_x6_wgrad() != 0 ? kBiasFromWgrad : 0;
   const bool fork = Nf > 0 && g_tune_coarse_stream.load() != 0 && side_stream_ready();
   hipStream_t sc = s;
   if (fork) {
@@ -639,9 +643,9 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
     sc = g_side_stream;
   }
   PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd0, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.mask, t.c.M, t.c.dz, t.c.dbias, live_c,
-                              cnt_bwd_c, sc, true));
+                              cnt_bwd_c, sc, true, bias_flags));
   PXO_TRY(launch_mlp_bwd_weights(cfg, t.c.acts, t.c.enc, t.c.dz, t.c.d_raw_rgb, t.c.d_raw_sigma, t.c.dbias, t.c.M,
-                                 grads, t.wgrad_ws, t.wgrad_bytes, live_c, sc));
+                                 grads, t.wgrad_ws, t.wgrad_bytes, live_c, sc, bias_flags));
   if (cfg->weight_decay_mult != 0.f) PXO_TRY(launch_axpy(grads, params, n_mlp, wd_coef, sc));
   if (grads0_ready && hipEventRecord((hipEvent_t)grads0_ready, sc) != hipSuccess) {
     set_error("pxo_train_fwd_bwd: hipEventRecord(grads0_ready) failed");
@@ -655,13 +659,13 @@ int pxo_train_fwd_bwd_bucketed(const PxoCfg* cfg, const float* params, const flo
     PXO_TRY(forward_fine(cfg, t, packed_fwd1, origins, directions, viewdirs, B, dr, pixels, nullptr, nullptr, nullptr, s,
                          cnt_fwd_f));
     PXO_TRY(launch_mlp_bwd_data(cfg, packed_bwd1, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.mask, t.f.M, t.f.dz, t.f.dbias, live_f,
-                                cnt_bwd_f, s, true));
+                                cnt_bwd_f, s, true, bias_flags));
     if (fork && hipStreamWaitEvent(s, g_ev_join, 0) != hipSuccess) {       // the slabs are the coarse pass's until here
       set_error("pxo_train_fwd_bwd: join of the side stream failed");
       return PXO_ERR_HIP;
     }
     PXO_TRY(launch_mlp_bwd_weights(cfg, t.f.acts, t.f.enc, t.f.dz, t.f.d_raw_rgb, t.f.d_raw_sigma, t.f.dbias, t.f.M,
-                                   grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, live_f, s));
+                                   grads + n_mlp, t.wgrad_ws, t.wgrad_bytes, live_f, s, bias_flags));
   } else {
     PXO_TRY(launch_fill(grads + n_mlp, n_mlp, 0.f, s));
   }

@@ -187,7 +187,12 @@ __host__ __device__ inline int64_t live_flags(int64_t M) { return (M + kLiveRows
 int launch_mlp_bwd_data(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb,
                         const float* d_raw_sigma, const uint32_t* mask, int64_t M, float* dz,
                         float* dbias_partial, uint8_t* chunk_live, unsigned int* tile_counter, hipStream_t s,
-                        bool counter_is_zero = false);
+                        bool counter_is_zero = false, int flags = 0);
+// flags of launch_mlp_bwd_data / launch_mlp_bwd_weights.  kBiasFromWgrad (bf16x6 with its own weight-gradient kernel only; the
+// train step sets it on BOTH launches of a pass): the bias gradients of Dense_1..7 are the column sums of dz_1..7 that
+// wgrad_x6_kernel takes while it streams dz -- backward(data) then skips its per-layer lane reductions for those layers
+// (6 % of its time) and the reduce reads the per-range sums instead of the per-slot partials.
+constexpr int kBiasFromWgrad = 1;
 // run-time choices between implementations of the same result (pxo_set_tuning; A/B sessions and equality tests)
 int tune_tile_sched();        // PXO_TUNE_TILE_SCHED: 0 static stride, 1 device counter (dense training kernels)
 int tune_wgrad_ranges();      // PXO_TUNE_WGRAD_RANGES: 0 = built-in choice, n > 0 = row ranges per layer of the 256x256 products
@@ -198,12 +203,12 @@ int tune_x6_wgrad();          // PXO_TUNE_X6_WGRAD: 1 (default) = in bf16x6 the 
 bool wgrad_skip_supported(int64_t M);
 // wgrad_x6_kernels.hip: the 256x256 products of Dense_1..7 in bf16x6 (same grid, slabs and reduce as the float32 launch)
 void launch_wgrad_main_x6(const float* acts, const float* dz1, int64_t M, int64_t rpw, int P, float* slab, int n_layers,
-                          int64_t layer_stride, const uint8_t* chunk_live, hipStream_t s);
+                          int64_t layer_stride, const uint8_t* chunk_live, float* dz_colsum, hipStream_t s);
 size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M);
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
-                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s);
+                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s, int flags = 0);
 int launch_count_live(const uint8_t* chunk_live, int64_t n, unsigned long long* out, hipStream_t s);
 int launch_posenc(const float* x, int64_t N, float* enc, hipStream_t s);
 // opt-in split-precision forward (mlp_x3_kernels.hip); pts == nullptr selects the dense-grid point source
@@ -218,7 +223,7 @@ int launch_mlp_fwd_x6(const PxoCfg* cfg, const float* packed_fwd, const float* p
                       uint32_t* mask, unsigned int* tile_counter, hipStream_t s);
 int launch_mlp_bwd_data_x6(const PxoCfg* cfg, const float* packed_bwd, const float* d_raw_rgb, const float* d_raw_sigma,
                            const uint32_t* mask, int64_t M, float* dz, float* dbias_partial, uint8_t* chunk_live,
-                           unsigned int* tile_counter, hipStream_t s);
+                           unsigned int* tile_counter, hipStream_t s, bool db_all = true);
 
 int launch_sample_along_rays(const float* o, const float* d, int64_t B, int S, float near_,
                              float far_, int lindisp, const float* t_rand, float* z, float* pts,

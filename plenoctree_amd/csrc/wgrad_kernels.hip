@@ -276,6 +276,8 @@ struct ReduceJobs {
   const float* dbias_partial;                   // + the bias gradients as job kDepth + 1: [slot][9][256] tile partials
   const uint8_t* tile_live;                     //   one byte per slot (0: the tile was skipped, its partial was not written)
   int64_t dbias_tiles;
+  const float* dz_colsum;                       //   bf16x6 with kBiasFromWgrad: Dense_1..7 from [layer - 1][range][256] instead
+  int colsum_ranges;
   int deg;
   float* grads;
 };
@@ -294,6 +296,11 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs J) {
     const int col = cg * 8 + c;
     const int64_t n = J.dbias_tiles;
     float s = 0.f;
+    if (J.dz_colsum && l >= 1 && l < kDepth) {
+      // the weight-gradient kernel's column sums of dz_l, one per row range: the same 32-way strided fixed-order sum
+      const float* __restrict__ src = J.dz_colsum + (int64_t)(l - 1) * J.colsum_ranges * kW + col;
+      for (int pp = tsub; pp < J.colsum_ranges; pp += 32) s += src[(int64_t)pp * kW];
+    } else
     for (int64_t t0 = tsub; t0 < n; t0 += 32 * 8) {
       bool lv[8];
       float v[8];
@@ -415,8 +422,9 @@ size_t wgrad_workspace_bytes(const PxoCfg* cfg, int64_t M) {
   // different M share one workspace)
   (void)cfg; (void)M;
   // Dense_1..7 in one launch: a slab set per layer; then the enc-based pair's and the heads' slabs (all reduced together)
+  // + the bf16x6 weight-gradient kernel's column sums of dz_1..7: [7][ranges][256]
   return ((size_t)(kDepth - 1) * num_cus() * kW * kW + (size_t)2 * num_cus() * kEncPad * 2 * kW +
-          (size_t)2 * num_cus() * kW * 32 * 3) * sizeof(float);
+          (size_t)2 * num_cus() * kW * 32 * 3 + (size_t)(kDepth - 1) * num_cus() * kW) * sizeof(float);
 }
 
 template <int NHB>
@@ -435,7 +443,7 @@ static void launch_head_wgrad(const float* X, const float* d_raw_rgb, const floa
 int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* enc, const float* dz,
                            const float* d_raw_rgb, const float* d_raw_sigma,
                            const float* dbias_partial, int64_t M, float* grads, void* ws,
-                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s) {
+                           size_t ws_bytes, const uint8_t* chunk_live, hipStream_t s, int flags) {
   if (M == 0) return PXO_OK;
   const int deg = cfg->sh_deg;
   const int C = rgb_channels(deg);
@@ -488,11 +496,17 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   float* const slab_main = reinterpret_cast<float*>(ws);
   float* const slab_enc = slab_main + (size_t)NL * num_cus() * kW * kW;
   float* const slab_head = slab_enc + (size_t)2 * num_cus() * kEncPad * 2 * kW;
+  float* const dz_colsum = slab_head + (size_t)2 * num_cus() * kW * 32 * 3;
+  const bool x6_main = cfg->mlp_precision == PXO_MLP_BF16X6 && tune_x6_wgrad() != 0;
+  if ((flags & kBiasFromWgrad) && !x6_main) {
+    set_error("mlp_bwd_weights: kBiasFromWgrad without the bf16x6 weight-gradient kernel");
+    return PXO_ERR_ARG;
+  }
   enc_pair(slab_enc);
   {
     KernelTimer timer(PXO_PROF_WGRAD_MAIN, M * NL, s);
-    if (cfg->mlp_precision == PXO_MLP_BF16X6 && tune_x6_wgrad() != 0)
-      launch_wgrad_main_x6(acts, dz + MW, M, rpwb, Pb, slab_main, NL, MW, chunk_live, s);
+    if (x6_main)
+      launch_wgrad_main_x6(acts, dz + MW, M, rpwb, Pb, slab_main, NL, MW, chunk_live, dz_colsum, s);
     else if (chunk_live)
       hipLaunchKernelGGL((wgrad_kernel<kW, kW, 2, 2, false, 256, 16, 2, false, 0, true>), dim3(NL * ((Pb + 7) / 8) * 16), dim3(256),
                          0, s, acts, dz + MW, nullptr, 0, M, rpwb, Pb, slab_main, nullptr, NL, MW, chunk_live);
@@ -510,6 +524,8 @@ int launch_mlp_bwd_weights(const PxoCfg* cfg, const float* acts, const float* en
   J.dbias_partial = dbias_partial;
   J.tile_live = dbias_tile_live(dbias_partial, M);
   J.dbias_tiles = (int64_t)mlp_bwd_partials(M);
+  J.dz_colsum = (flags & kBiasFromWgrad) ? dz_colsum : nullptr;
+  J.colsum_ranges = Pb;
   J.deg = deg;
   J.grads = grads;
   // (Issuing the coarse pass's reduction on a lowest-priority side stream, to run in the tail of the fine pass's backward

@@ -11,7 +11,8 @@
 // x 16 bytes -- which is what both MFMA operands of a "TN" product want: a lane's A fragment is 8 rows of one input feature,
 // its B fragment 8 rows of one output column.  A thread owns (one column, one k-block) of X and of dZ: 8 + 8 dword loads with
 // the lanes along the row (256-byte wave loads), each group of 8 a whole fragment: one ds_write_b128 per part, conflict-free
-// both ways.  (A first version with two 4-wave workgroups per range -- column halves, X split twice -- gave the same bits
+// both ways.  While it streams dZ the kernel also sums its columns per range: the bias gradients of Dense_1..7 (kBiasFromWgrad in
+// pxo_common.h; backward(data) then drops its lane reductions for those layers, 6 % of its time).  (A first version with two 4-wave workgroups per range -- column halves, X split twice -- gave the same bits
 // and was 7 % slower: 2.63 vs 2.44 ms per launch.)
 #include "pxo_common.h"
 #include "pxo_x6.h"
@@ -27,7 +28,8 @@ static_assert(kGK == 16, "one v_mfma_f32_32x32x16_bf16 per chunk and block");
 template <bool SPARSE>
 __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     const float* __restrict__ X, const float* __restrict__ dZ, int64_t M, int64_t rows_per_wg, int P,
-    float* __restrict__ slab, int n_layers, int64_t layer_stride, const uint8_t* __restrict__ chunk_live) {
+    float* __restrict__ slab, int n_layers, int64_t layer_stride, const uint8_t* __restrict__ chunk_live,
+    float* __restrict__ dz_colsum) {
   __shared__ __attribute__((aligned(16))) bf16x8 xs[2][3][2][kW];
   __shared__ __attribute__((aligned(16))) bf16x8 zs[2][3][2][kW];
 
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
     X += (int64_t)g * layer_stride;
     dZ += (int64_t)g * layer_stride;
     slab += (int64_t)g * P * kW * kW;
+    dz_colsum += (int64_t)g * P * kW;
   }
   if (p >= P) return;
   const int64_t r_begin = (int64_t)p * rows_per_wg;
@@ -91,9 +94,18 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
 
+  // column sums of dZ over the range (= this range's share of the layer's bias gradient): this thread's 8 rows of every chunk,
+  // in chunk order; the two k-blocks of a column meet in LDS at the end
+  float zsum = 0.f;
+  // (row order, one accumulator, `on` = 1 or 0 as a FACTOR: no temporaries and no branch -- the kernel sits at its register limit
+  // and a chunk is one scheduling region)
+  auto colsum8 = [&](const float* v, float on) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zsum = __builtin_fmaf(on, v[i], zsum);
+  };
   const int kb = lane >> 5, l32 = lane & 31;
   // chunk `buf` is multiplied; the loads of chunk + 1 are issued first and split / stored to the other buffer behind the MFMAs
-  auto run_chunk = [&](int buf, Stage& st, int ld_ch) {
+  auto run_chunk = [&](int buf, Stage& st, int ld_ch, float more) {
     load_chunk(ld_ch, st);
     bf16x8 b[CB][3];
 #pragma unroll
@@ -127,7 +139,10 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
       // the next chunk's split: X behind the second row block's MFMAs, dZ behind the third's (measured, ms per launch: one block
       // earlier 2.42 -- the loads have not landed --, one later 2.37, at the end 2.38, this 2.29)
       if (r == 1) put(xs[buf ^ 1], split8(st.x));
-      if (r == 2) put(zs[buf ^ 1], split8(st.z));
+      if (r == 2) {
+        put(zs[buf ^ 1], split8(st.z));
+        colsum8(st.z, more);                   // (past the end the last chunk is staged a second time: not summed again)
+      }
 #pragma unroll
       for (int c = 0; c < CB; ++c) acc[r][c] += t[c];
     }
@@ -165,11 +180,19 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
       load_chunk(chunk_at(0), st);
       put(xs[0], split8(st.x));
       put(zs[0], split8(st.z));
+      colsum8(st.z, 1.f);
     }
     __syncthreads();
-    for (int i = 0; i < n_run; ++i) run_chunk(i & 1, st, chunk_at(i + 1 < n_run ? i + 1 : i));
+    for (int i = 0; i < n_run; ++i) run_chunk(i & 1, st, chunk_at(i + 1 < n_run ? i + 1 : i), i + 1 < n_run ? 1.f : 0.f);
   }
 
+  // the range's column sums: the two k-block partials of a column through LDS (the chunk buffers are free after the last barrier)
+  {
+    float* zsum_lds = reinterpret_cast<float*>(&xs[0][0][0][0]);
+    if (skb == 1) zsum_lds[sc] = zsum;
+    __syncthreads();
+    if (skb == 0) dz_colsum[(int64_t)p * kW + sc] = zsum + zsum_lds[sc];
+  }
   float* out = slab + (int64_t)p * kW * kW;
 #pragma unroll
   for (int r = 0; r < RB; ++r)
@@ -186,13 +209,13 @@ __global__ __launch_bounds__(kGThreads, 2) void wgrad_x6_kernel(
 
 // grid / argument conventions of the float32 launch it replaces (launch_mlp_bwd_weights)
 void launch_wgrad_main_x6(const float* acts, const float* dz1, int64_t M, int64_t rpw, int P, float* slab, int n_layers,
-                          int64_t layer_stride, const uint8_t* chunk_live, hipStream_t s) {
+                          int64_t layer_stride, const uint8_t* chunk_live, float* dz_colsum, hipStream_t s) {
   const dim3 grid(n_layers * P), block(kGThreads);
   if (chunk_live)
-    hipLaunchKernelGGL((wgrad_x6_kernel<true>), grid, block, 0, s, acts, dz1, M, rpw, P, slab, n_layers, layer_stride, chunk_live);
+    hipLaunchKernelGGL((wgrad_x6_kernel<true>), grid, block, 0, s, acts, dz1, M, rpw, P, slab, n_layers, layer_stride, chunk_live, dz_colsum);
   else
     hipLaunchKernelGGL((wgrad_x6_kernel<false>), grid, block, 0, s, acts, dz1, M, rpw, P, slab, n_layers, layer_stride,
-                       (const uint8_t*)nullptr);
+                       (const uint8_t*)nullptr, dz_colsum);
 }
 
 }  // namespace pxo

@@ -276,6 +276,36 @@ def _train_step(ops, dev, pcfg, cfg, flat, B, seed=3, poison=False):
     return grads.cpu(), stats.cpu(), (live, total), (rays, px, t_rand, u, sp)
 
 
+@pytest.mark.parametrize("deg", [3, 4])
+def test_bias_gradients_from_the_weight_gradient_kernel(deg):
+    """In the train step bf16x6's weight-gradient kernel also delivers the bias gradients of Dense_1..7 (column sums of dz_1..7
+    taken while it streams them; backward(data) then leaves its lane reductions for those layers out).  Against the same step
+    with PXO_TUNE_X6_WGRAD = 0 (float32 weight-gradient kernel, bias gradients from backward(data)'s per-tile partials): the
+    same sums in another order."""
+    ops = _ops(); dev = _gpu()
+    cfg = O.Cfg(sh_deg=deg)
+    _, cx6 = _cfgs(ops, cfg)
+    flat = make_params(cfg, bias_scale=0.2)
+    g = {}
+    try:
+        for knob in (1, 0):
+            ops.set_tuning(ops.TUNE_X6_WGRAD, knob)
+            g[knob] = _train_step(ops, dev, cx6, cfg, flat, 96, poison=True)[0]
+    finally:
+        ops.set_tuning(ops.TUNE_X6_WGRAD, 1)
+    assert torch.isfinite(g[1]).all()
+    lay, n = ops.param_layout(cx6)
+    for mi in range(2):
+        for layer, is_bias, o, rows, cols in lay:
+            a = g[1][mi * n + o: mi * n + o + rows * cols].double()
+            b = g[0][mi * n + o: mi * n + o + rows * cols].double()
+            scale = float(b.abs().max())
+            if is_bias and 1 <= layer <= 7:
+                assert scale > 0 and float((a - b).abs().max()) <= 2e-6 * scale + 1e-12, (mi, layer, float((a - b).abs().max()), scale)
+            elif is_bias or layer in (0, 8, 9):
+                assert torch.equal(a, b), (mi, layer, is_bias)          # Dense_0 / heads / their biases: the same kernels, same bits
+
+
 @pytest.mark.parametrize("deg,Nf", [(3, 128), (4, 128), (3, 0)])
 def test_train_step_x6_matches_oracle(deg, Nf):
     """pxo_train_fwd_bwd in bf16x6 against loss_fn + value_and_grad of the float64 oracle: as close as the float32 path."""

@@ -11,8 +11,9 @@
 // kernel's chain -- the result is CLOSER to the float64 product than the float32 kernel's (tests/test_gpu_x6.py).
 //
 // What stays float32: everything that leaves the kernels.  acts / enc / dz / raw_* / bias partials are float32 row-major
-// arrays in the layouts of mlp_kernels.hip, so the weight-gradient GEMMs (wgrad_kernels.hip, native float32 MFMA), the
-// compositing kernels and the workspace are untouched; only the relu-mask words are in this file's own order.
+// arrays in the layouts of mlp_kernels.hip, so the weight-gradient kernels (the 256x256 products: wgrad_x6_kernels.hip, which
+// splits those float32 arrays itself; the skinny ones: wgrad_kernels.hip, native float32 MFMA), the compositing kernels and the
+// workspace are untouched; only the relu-mask words are in this file's own order.
 //
 // Replaces posenc + MLP.__call__ (nerf_sh/nerf/model_utils.py:43-94,145-173) and its reverse (jax.value_and_grad,
 // nerf_sh/train.py:116) for the same configurations as mlp_fwd_kernel / mlp_bwd_data_kernel.
